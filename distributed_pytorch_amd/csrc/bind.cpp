@@ -1,0 +1,193 @@
+// pybind11 surface of the native library.  Tensors cross as raw device addresses (integers from
+// torch.Tensor.data_ptr()) and the stream as the hipStream_t of torch's current stream, so this
+// file needs no torch headers and the extension builds in seconds with plain hipcc.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "kernels/kernels.h"
+#include "comm/comm.h"
+
+namespace py = pybind11;
+using namespace dpa;
+
+namespace {
+template <typename T> T* ptr(uintptr_t p) { return reinterpret_cast<T*>(p); }
+hipStream_t st(uintptr_t s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+PYBIND11_MODULE(_C, m) {
+  m.doc() = "distributed_pytorch_amd native kernels + comm runtime (gfx950 / MI355X)";
+  m.attr("F32") = (int)kF32;
+  m.attr("BF16") = (int)kBF16;
+  m.attr("F16") = (int)kF16;
+  m.attr("IGEMM_RELU") = (int)kIgemmRelu;
+  m.attr("IGEMM_SCATTER") = (int)kIgemmScatter;
+
+  m.def("igemm",
+        [](uintptr_t A, uintptr_t B, uintptr_t C, uintptr_t bias, uintptr_t stats, uintptr_t taps, int M, int N,
+           int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
+           int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream) {
+          IgemmParams p;
+          p.A = ptr<const void>(A);
+          p.B = ptr<const void>(B);
+          p.C = ptr<void>(C);
+          p.bias = ptr<const float>(bias);
+          p.stats = ptr<float>(stats);
+          p.taps = ptr<const int>(taps);
+          p.M = M; p.N = N; p.Cred = Cred; p.ntaps = ntaps;
+          p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+          p.IH = IH; p.IW = IW; p.SY = SY; p.SX = SX;
+          p.OHF = OHF; p.OWF = OWF; p.OSY = OSY; p.OSX = OSX; p.OY0 = OY0; p.OX0 = OX0;
+          p.flags = flags;
+          p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
+          p.div_ow = make_fastdiv((uint32_t)OW);
+          igemm_launch(p, dtype, out_dtype, st(stream));
+        });
+  m.def("igemm_tile_m", &igemm_tile_m);
+
+  m.def("wgrad_choose_splits", [](long M, int N, int Ktot, int dtype) {
+    int pps = 0;
+    const int s = wgrad_choose_splits(M, N, Ktot, dtype, &pps);
+    return py::make_tuple(s, pps);
+  });
+  m.def("wgrad",
+        [](uintptr_t dY, uintptr_t X, uintptr_t slab, uintptr_t taps, int M, int N, int Cred, int ntaps, int ldy,
+           int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int dtype, uintptr_t stream) {
+          WgradParams p;
+          p.dY = ptr<const void>(dY);
+          p.X = ptr<const void>(X);
+          p.slab = ptr<float>(slab);
+          p.taps = ptr<const int>(taps);
+          p.M = M; p.N = N; p.Cred = Cred; p.ntaps = ntaps; p.Ktot = ntaps * Cred;
+          p.ldy = ldy; p.ldx = ldx; p.IH = IH; p.IW = IW; p.SY = SY; p.SX = SX;
+          p.splits = splits; p.pix_per_split = pps;
+          p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
+          p.div_ow = make_fastdiv((uint32_t)OW);
+          wgrad_launch(p, dtype, st(stream));
+        });
+  m.def("slab_reduce", [](uintptr_t slab, int splits, long n, uintptr_t out, int out_dtype, float beta, uintptr_t s) {
+    slab_reduce_launch(ptr<const float>(slab), splits, n, ptr<void>(out), out_dtype, beta, st(s));
+  });
+
+  // ---- batch norm
+  m.def("bn_partial_rows", &bn_partial_rows);
+  m.def("bn_stats", [](uintptr_t x, long M, int C, int dtype, uintptr_t partial, int nblk, uintptr_t s) {
+    bn_stats_launch(ptr<const void>(x), M, C, dtype, ptr<float>(partial), nblk, st(s));
+  });
+  m.def("bn_finalize", [](uintptr_t partial, int nparts, int C, double count, uintptr_t gamma, uintptr_t beta,
+                          float eps, float momentum, uintptr_t rm, uintptr_t rv, uintptr_t nbt, uintptr_t mean,
+                          uintptr_t invstd, uintptr_t scale, uintptr_t shift, uintptr_t s) {
+    bn_finalize_launch(ptr<const float>(partial), nparts, C, count, ptr<const float>(gamma), ptr<const float>(beta),
+                       eps, momentum, ptr<float>(rm), ptr<float>(rv), ptr<long>(nbt), ptr<float>(mean),
+                       ptr<float>(invstd), ptr<float>(scale), ptr<float>(shift), st(s));
+  });
+  m.def("bn_eval_coeffs", [](uintptr_t gamma, uintptr_t beta, uintptr_t rm, uintptr_t rv, float eps, int C,
+                             uintptr_t scale, uintptr_t shift, uintptr_t s) {
+    bn_eval_coeffs_launch(ptr<const float>(gamma), ptr<const float>(beta), ptr<const float>(rm), ptr<const float>(rv),
+                          eps, C, ptr<float>(scale), ptr<float>(shift), st(s));
+  });
+  m.def("bn_apply", [](uintptr_t x, uintptr_t res, uintptr_t y, long M, int C, int dtype, uintptr_t scale,
+                       uintptr_t shift, int relu, uintptr_t s) {
+    bn_apply_launch(ptr<const void>(x), ptr<const void>(res), ptr<void>(y), M, C, dtype, ptr<const float>(scale),
+                    ptr<const float>(shift), relu, st(s));
+  });
+  m.def("bn_bwd_reduce", [](uintptr_t dy, uintptr_t x, uintptr_t y, long M, int C, int dtype, uintptr_t mean,
+                            uintptr_t invstd, int relu, uintptr_t partial, int nblk, uintptr_t s) {
+    bn_bwd_reduce_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const void>(y), M, C, dtype,
+                         ptr<const float>(mean), ptr<const float>(invstd), relu, ptr<float>(partial), nblk, st(s));
+  });
+  m.def("bn_bwd_finalize", [](uintptr_t partial, int nparts, int C, uintptr_t dgamma, uintptr_t dbeta, uintptr_t s) {
+    bn_bwd_finalize_launch(ptr<const float>(partial), nparts, C, ptr<float>(dgamma), ptr<float>(dbeta), st(s));
+  });
+  m.def("bn_bwd_apply", [](uintptr_t dy, uintptr_t x, uintptr_t y, uintptr_t dx, uintptr_t dres, long M, int C,
+                           int dtype, uintptr_t mean, uintptr_t invstd, uintptr_t gamma, uintptr_t dgamma,
+                           uintptr_t dbeta, double count, int relu, uintptr_t s) {
+    bn_bwd_apply_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const void>(y), ptr<void>(dx), ptr<void>(dres), M,
+                        C, dtype, ptr<const float>(mean), ptr<const float>(invstd), ptr<const float>(gamma),
+                        ptr<const float>(dgamma), ptr<const float>(dbeta), count, relu, st(s));
+  });
+
+  // ---- pooling
+  m.def("maxpool_fwd", [](uintptr_t x, uintptr_t y, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw,
+                          int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
+    maxpool_fwd_launch(ptr<const void>(x), ptr<void>(y), NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype, st(s));
+  });
+  m.def("maxpool_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, int NB, int IH, int IW, int C, int OH, int OW,
+                          int kh, int kw, int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
+    maxpool_bwd_launch(ptr<const void>(x), ptr<const void>(dy), ptr<void>(dx), NB, IH, IW, C, OH, OW, kh, kw, sh, sw,
+                       ph, pw, dtype, st(s));
+  });
+  m.def("avgpool_fwd", [](uintptr_t x, uintptr_t y, int NB, int IH, int IW, int C, int OH, int OW, int dtype,
+                          uintptr_t s) {
+    avgpool_fwd_launch(ptr<const void>(x), ptr<void>(y), NB, IH, IW, C, OH, OW, dtype, st(s));
+  });
+  m.def("avgpool_bwd", [](uintptr_t dy, uintptr_t dx, int NB, int IH, int IW, int C, int OH, int OW, int dtype,
+                          uintptr_t s) {
+    avgpool_bwd_launch(ptr<const void>(dy), ptr<void>(dx), NB, IH, IW, C, OH, OW, dtype, st(s));
+  });
+
+  // ---- loss
+  m.def("xent_fwd_bwd", [](uintptr_t logits, uintptr_t target, int N, int C, int ldl, int dtype, uintptr_t loss,
+                           uintptr_t dlogits, uintptr_t rowbuf, uintptr_t metrics, uintptr_t s) {
+    xent_fwd_bwd_launch(ptr<const void>(logits), ptr<const long>(target), N, C, ldl, dtype, ptr<float>(loss),
+                        ptr<void>(dlogits), ptr<float>(rowbuf), ptr<float>(metrics), st(s));
+  });
+  m.def("xent_bwd_scale", [](uintptr_t dlogits, long n, int dtype, uintptr_t gout, uintptr_t s) {
+    xent_bwd_scale_launch(ptr<void>(dlogits), n, dtype, ptr<const float>(gout), st(s));
+  });
+
+  // ---- elementwise
+  m.def("normalize_u8", [](uintptr_t x, uintptr_t y, long npix, int cin, int cout, int hw, int nchw, uintptr_t mean,
+                           uintptr_t istd, int dtype, uintptr_t s) {
+    normalize_u8_launch(ptr<const uint8_t>(x), ptr<void>(y), npix, cin, cout, hw, nchw, ptr<const float>(mean),
+                        ptr<const float>(istd), dtype, st(s));
+  });
+  m.def("nchw_to_nhwc", [](uintptr_t x, uintptr_t y, int NB, int C, int HW, int cpad, int in_dtype, int out_dtype,
+                           uintptr_t s) {
+    nchw_to_nhwc_launch(ptr<const void>(x), ptr<void>(y), NB, C, HW, cpad, in_dtype, out_dtype, st(s));
+  });
+  m.def("relu_fwd", [](uintptr_t x, uintptr_t y, long n, int dtype, uintptr_t s) {
+    relu_fwd_launch(ptr<const void>(x), ptr<void>(y), n, dtype, st(s));
+  });
+  m.def("relu_bwd", [](uintptr_t y, uintptr_t dy, uintptr_t dx, long n, int dtype, uintptr_t s) {
+    relu_bwd_launch(ptr<const void>(y), ptr<const void>(dy), ptr<void>(dx), n, dtype, st(s));
+  });
+  m.def("add_relu_fwd", [](uintptr_t a, uintptr_t b, uintptr_t y, long n, int dtype, uintptr_t s) {
+    add_relu_fwd_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(y), n, dtype, st(s));
+  });
+  m.def("dropout_fwd", [](uintptr_t x, uintptr_t y, uintptr_t mask, long n, float p, uint64_t seed, uint64_t offset,
+                          int dtype, uintptr_t s) {
+    dropout_fwd_launch(ptr<const void>(x), ptr<void>(y), ptr<uint8_t>(mask), n, p, seed, offset, dtype, st(s));
+  });
+  m.def("dropout_bwd", [](uintptr_t dy, uintptr_t mask, uintptr_t dx, long n, float p, int dtype, uintptr_t s) {
+    dropout_bwd_launch(ptr<const void>(dy), ptr<const uint8_t>(mask), ptr<void>(dx), n, p, dtype, st(s));
+  });
+  m.def("cast", [](uintptr_t x, int in_dtype, uintptr_t y, int out_dtype, long n, uintptr_t s) {
+    cast_launch(ptr<const void>(x), in_dtype, ptr<void>(y), out_dtype, n, st(s));
+  });
+  m.def("transpose_ktc", [](uintptr_t w, uintptr_t wt, int K, int T, int C, int in_dtype, int out_dtype, uintptr_t s) {
+    transpose_ktc_launch(ptr<const void>(w), ptr<void>(wt), K, T, C, in_dtype, out_dtype, st(s));
+  });
+  m.def("axpby", [](uintptr_t x, int x_dtype, uintptr_t y, long n, float alpha, float beta, uintptr_t s) {
+    axpby_launch(ptr<const void>(x), x_dtype, ptr<float>(y), n, alpha, beta, st(s));
+  });
+
+  // ---- optimizer / loss scaler
+  m.def("sgd_chunk_elems", &sgd_chunk_elems);
+  m.def("sgd_table_entry_bytes", []() { return (int)sizeof(SgdTensor); });
+  m.def("sgd_multi_tensor", [](uintptr_t table, int ntensors, long total_chunks, int g_dtype, int lp_dtype,
+                               uintptr_t hyper, uintptr_t inv_scale, uintptr_t found_inf, uintptr_t s) {
+    sgd_multi_tensor_launch(ptr<const SgdTensor>(table), ntensors, total_chunks, g_dtype, lp_dtype,
+                            ptr<const float>(hyper), ptr<const float>(inv_scale), ptr<const float>(found_inf), st(s));
+  });
+  m.def("check_finite", [](uintptr_t g, long n, int dtype, uintptr_t found_inf, uintptr_t s) {
+    check_finite_flat_launch(ptr<const void>(g), n, dtype, ptr<float>(found_inf), st(s));
+  });
+  m.def("scaler_update", [](uintptr_t scale, uintptr_t inv_scale, uintptr_t good, uintptr_t found_inf, int interval,
+                            float growth, float backoff, float max_scale, float min_scale, uintptr_t s) {
+    scaler_update_launch(ptr<float>(scale), ptr<float>(inv_scale), ptr<int>(good), ptr<float>(found_inf), interval,
+                         growth, backoff, max_scale, min_scale, st(s));
+  });
+
+  bind_comm(m);
+}

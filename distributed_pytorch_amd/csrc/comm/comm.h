@@ -1,0 +1,4 @@
+// RCCL-over-xGMI communication runtime: communicator + bucketed gradient reducer.
+#pragma once
+#include <pybind11/pybind11.h>
+void bind_comm(pybind11::module_& m);

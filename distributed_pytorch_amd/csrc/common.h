@@ -1,0 +1,129 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Everything here assumes wave64 and the gfx950 MFMA operand layouts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+
+namespace dpa {
+
+enum DType : int { kF32 = 0, kBF16 = 1, kF16 = 2 };
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+// ---- scalar conversions ------------------------------------------------------------------
+__device__ __forceinline__ float to_float(float x) { return x; }
+__device__ __forceinline__ float to_float(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float to_float(f16_t x) { return (float)x.v; }
+
+template <typename T> __device__ __forceinline__ T from_float(float x);
+template <> __device__ __forceinline__ float from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_float<bf16_t>(float x) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  __bf16 b = (__bf16)x;
+  bf16_t r;
+  __builtin_memcpy(&r.v, &b, 2);
+  return r;
+}
+template <> __device__ __forceinline__ f16_t from_float<f16_t>(float x) {
+  f16_t r;
+  r.v = (_Float16)x;
+  return r;
+}
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float> { static constexpr int kVec = 4; static constexpr int kCode = kF32; };
+template <> struct TypeInfo<bf16_t> { static constexpr int kVec = 8; static constexpr int kCode = kBF16; };
+template <> struct TypeInfo<f16_t> { static constexpr int kVec = 8; static constexpr int kCode = kF16; };
+
+// 16-byte vector <-> fp32 lanes
+template <typename T> struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  uint4 raw;
+  __device__ __forceinline__ void load(const void* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const {
+    T t;
+    __builtin_memcpy(&t, reinterpret_cast<const char*>(&raw) + i * sizeof(T), sizeof(T));
+    return to_float(t);
+  }
+  __device__ __forceinline__ void set(int i, float f) {
+    T t = from_float<T>(f);
+    __builtin_memcpy(reinterpret_cast<char*>(&raw) + i * sizeof(T), &t, sizeof(T));
+  }
+};
+
+// ---- fast unsigned division by a runtime constant (host computes the magic) ---------------
+struct FastDiv {
+  uint32_t d, magic, shift;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) {
+    f.magic = 0;
+    f.shift = 0;
+    return f;
+  }
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+  f.magic = (uint32_t)m;
+  f.shift = l;
+  return f;
+}
+// exact for all n < 2^31
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  uint32_t t = __umulhi(n, f.magic);
+  return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD one contiguous chunk of the logical tile space (L2 reuse of the
+// operand panels shared by neighbouring tiles).  Speed only, never correctness.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+  const uint32_t q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  const uint32_t base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + i;
+}
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace dpa
+
+// dtype dispatch: binds `T` inside the statement block
+#define DPA_DISPATCH_DTYPE(dtype, ...)                                   \
+  switch (dtype) {                                                       \
+    case ::dpa::kF32: { using T = float; __VA_ARGS__; break; }           \
+    case ::dpa::kBF16: { using T = ::dpa::bf16_t; __VA_ARGS__; break; }  \
+    case ::dpa::kF16: { using T = ::dpa::f16_t; __VA_ARGS__; break; }    \
+    default: throw std::invalid_argument("unsupported dtype");           \
+  }
+
+#define DPA_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)

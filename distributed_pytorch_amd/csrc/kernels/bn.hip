@@ -1,0 +1,348 @@
+// BatchNorm (+ residual add, + ReLU) forward / backward for NHWC activations on gfx950.
+//
+// NHWC makes the channel the fast axis, so per-channel statistics are COLUMN reductions: every
+// thread owns one 16-byte channel chunk and walks rows; partial sums leave each workgroup as an
+// fp32 slab [block][2][C] that a tiny finalize kernel folds in a fixed order (deterministic, no
+// float atomics).  Statistics are always fp32 (double in the final fold).
+//
+// forward  (train): stats -> finalize (mean, invstd, scale/shift, running stats) -> apply
+// forward  (eval) : eval_coeffs -> apply
+// backward        : bwd_reduce (sum dy, sum dy*xhat with the ReLU mask recomputed from y)
+//                   -> bwd_finalize -> bwd_apply (dx, optional masked copy for the residual branch)
+// SyncBatchNorm reuses the same kernels with an all-reduce between the reduce and finalize steps
+// (parallel/sync_batchnorm.py).
+//
+// Replaces cuDNN BatchNorm + ATen ReLU/add kernels and Apex's syncbn extension
+// (reference imagenet_ddp_apex.py:146-148) -- SURVEY.md N-K4..N-K7.
+#include "../common.h"
+#include "kernels.h"
+#include <stdexcept>
+
+namespace dpa {
+namespace {
+
+constexpr int kBnThreads = 256;
+
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum dy_m, sum dy_m * xhat) with dy_m = dy * (y > 0) if relu.
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ x,
+                                                                const T* __restrict__ y, long M, int C,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu,
+                                                                float* __restrict__ partial, long rows_per_block) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float red[2][kBnThreads * VEC];
+  const int cc_total = C / VEC;
+  const int cc0 = blockIdx.y * kBnThreads;
+  const int ccb = min(cc_total - cc0, kBnThreads);        // chunk columns in this block
+  const int rp = kBnThreads / ccb;                          // row lanes
+  const int tid = threadIdx.x;
+  const int col = tid % ccb, rl = tid / ccb;
+  const bool active = rl < rp;
+  const int c0 = (cc0 + col) * VEC;
+
+  float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    s1[j] = s2[j] = 0.f;
+    mu[j] = 0.f;
+    is[j] = 1.f;
+  }
+  if (MODE == 1 && active) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mu[j] = mean[c0 + j];
+      is[j] = invstd[c0 + j];
+    }
+  }
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(M, r_begin + rows_per_block);
+  if (active) {
+    for (long r = r_begin + rl; r < r_end; r += rp) {
+      const size_t off = (size_t)r * C + c0;
+      Vec16<T> va;
+      va.load(a + off);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float f = va.get(j);
+          s1[j] += f;
+          s2[j] += f * f;
+        }
+      } else {
+        Vec16<T> vx, vy;
+        vx.load(x + off);
+        if (relu) vy.load(y + off);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float d = va.get(j);
+          if (relu && !(vy.get(j) > 0.f)) d = 0.f;
+          const float xh = (vx.get(j) - mu[j]) * is[j];
+          s1[j] += d;
+          s2[j] += d * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[0][tid * VEC + j] = s1[j];
+    red[1][tid * VEC + j] = s2[j];
+  }
+  __syncthreads();
+  // thread t < ccb*VEC sums channel (t) over row lanes
+  for (int t = tid; t < ccb * VEC; t += kBnThreads) {
+    const int cchunk = t / VEC, j = t - cchunk * VEC;
+    float a1 = 0.f, a2 = 0.f;
+    for (int q = 0; q < rp; ++q) {
+      a1 += red[0][(q * ccb + cchunk) * VEC + j];
+      a2 += red[1][(q * ccb + cchunk) * VEC + j];
+    }
+    const int c = cc0 * VEC + t;
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a1;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = a2;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var,
+                                   long* num_batches_tracked, float* mean, float* invstd, float* scale,
+                                   float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nparts; ++k) {
+    s1 += (double)partial[((size_t)k * 2 + 0) * C + c];
+    s2 += (double)partial[((size_t)k * 2 + 1) * C + c];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m;
+  invstd[c] = is;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - (float)m * g * is;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - rm[c] * g * is;
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, float* o1, float* o2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nparts; ++k) {
+    s1 += (double)partial[((size_t)k * 2 + 0) * C + c];
+    s2 += (double)partial[((size_t)k * 2 + 1) * C + c];
+  }
+  o1[c] = (float)s1;
+  o2[c] = (float)s2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                       T* __restrict__ y, long nchunks, int cc,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int relu) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+    const int c0 = (int)(i % cc) * VEC;
+    Vec16<T> vx, vr, vo;
+    vx.load(x + i * VEC);
+    if (res != nullptr) vr.load(res + i * VEC);
+    const float4* sc = reinterpret_cast<const float4*>(scale + c0);
+    const float4* sh = reinterpret_cast<const float4*>(shift + c0);
+    float scv[VEC], shv[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 a = sc[q], b = sh[q];
+      scv[4 * q] = a.x; scv[4 * q + 1] = a.y; scv[4 * q + 2] = a.z; scv[4 * q + 3] = a.w;
+      shv[4 * q] = b.x; shv[4 * q + 1] = b.y; shv[4 * q + 2] = b.z; shv[4 * q + 3] = b.w;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = vx.get(j) * scv[j] + shv[j];
+      if (res != nullptr) v += vr.get(j);
+      if (relu) v = fmaxf(v, 0.f);
+      vo.set(j, v);
+    }
+    vo.store(y + i * VEC);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, T* __restrict__ dx,
+                                                           T* __restrict__ dres, long nchunks, int cc,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float inv_count,
+                                                           int relu) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+    const int c0 = (int)(i % cc) * VEC;
+    Vec16<T> vd, vx, vy, vo, vr;
+    vd.load(dy + i * VEC);
+    vx.load(x + i * VEC);
+    if (relu) vy.load(y + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      float d = vd.get(j);
+      if (relu && !(vy.get(j) > 0.f)) d = 0.f;
+      const float is = invstd[c];
+      const float xh = (vx.get(j) - mean[c]) * is;
+      const float g = gamma ? gamma[c] : 1.f;
+      const float v = g * is * (d - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
+      vo.set(j, v);
+      vr.set(j, d);
+    }
+    vo.store(dx + i * VEC);
+    if (dres != nullptr) vr.store(dres + i * VEC);
+  }
+}
+
+inline int grid_for(long nchunks) {
+  long b = (nchunks + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;
+  return (int)(b < 1 ? 1 : b);
+}
+
+void check_c(int C, int dtype) {
+  const int vec = dtype == kF32 ? 4 : 8;
+  if (C % vec != 0) throw std::invalid_argument("bn: C must be a multiple of 16 bytes");
+}
+
+template <int MODE>
+void col_reduce(const void* a, const void* x, const void* y, long M, int C, int dtype, const float* mean,
+                const float* invstd, int relu, float* partial, int nblk, hipStream_t s) {
+  check_c(C, dtype);
+  const int vec = dtype == kF32 ? 4 : 8;
+  const int gy = ceil_div(C / vec, kBnThreads);
+  const long rpb = (M + nblk - 1) / nblk;
+  dim3 grid(nblk, gy);
+  if (dtype == kF32)
+    hipLaunchKernelGGL((col_reduce_kernel<float, MODE>), grid, dim3(kBnThreads), 0, s, (const float*)a,
+                       (const float*)x, (const float*)y, M, C, mean, invstd, relu, partial, rpb);
+  else if (dtype == kBF16)
+    hipLaunchKernelGGL((col_reduce_kernel<bf16_t, MODE>), grid, dim3(kBnThreads), 0, s, (const bf16_t*)a,
+                       (const bf16_t*)x, (const bf16_t*)y, M, C, mean, invstd, relu, partial, rpb);
+  else
+    hipLaunchKernelGGL((col_reduce_kernel<f16_t, MODE>), grid, dim3(kBnThreads), 0, s, (const f16_t*)a,
+                       (const f16_t*)x, (const f16_t*)y, M, C, mean, invstd, relu, partial, rpb);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+int bn_partial_rows(long M, int C) {
+  // enough row blocks to fill the chip (~4 workgroups per CU over all column groups), >= 64 rows each
+  const int gy = ceil_div(C / 4, kBnThreads * 2) > 0 ? ceil_div(C / 8, kBnThreads) : 1;
+  long nblk = 1024 / (gy > 0 ? gy : 1);
+  const long max_by_rows = (M + 63) / 64;
+  if (nblk > max_by_rows) nblk = max_by_rows;
+  if (nblk < 1) nblk = 1;
+  return (int)nblk;
+}
+
+void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, int nblk, hipStream_t s) {
+  col_reduce<0>(x, nullptr, nullptr, M, C, dtype, nullptr, nullptr, 0, partial, nblk, s);
+}
+
+void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, int C, int dtype,
+                          const float* mean, const float* invstd, int relu, float* partial, int nblk,
+                          hipStream_t s) {
+  col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu, partial, nblk, s);
+}
+
+void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, long* num_batches_tracked, float* mean, float* invstd,
+                        float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partial, nparts, C, count,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd,
+                     scale, shift);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, int C, float* scale, float* shift,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
+                            hipStream_t s) {
+  // partial[.][0] = sum dy (dbeta), partial[.][1] = sum dy*xhat (dgamma)
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partial, nparts, C, dbeta,
+                     dgamma);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
+                     const float* scale, const float* shift, int relu, hipStream_t s) {
+  check_c(C, dtype);
+  const int vec = dtype == kF32 ? 4 : 8;
+  const long nchunks = M * (C / vec);
+  if (nchunks <= 0) return;
+  const int grid = grid_for(nchunks);
+  if (dtype == kF32)
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x,
+                       (const float*)residual, (float*)y, nchunks, C / vec, scale, shift, relu);
+  else if (dtype == kBF16)
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)residual, (bf16_t*)y, nchunks, C / vec, scale, shift, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)x,
+                       (const f16_t*)residual, (f16_t*)y, nchunks, C / vec, scale, shift, relu);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
+                         int C, int dtype, const float* mean, const float* invstd,
+                         const float* gamma, const float* dgamma, const float* dbeta, double count,
+                         int relu, hipStream_t s) {
+  check_c(C, dtype);
+  const int vec = dtype == kF32 ? 4 : 8;
+  const long nchunks = M * (C / vec);
+  if (nchunks <= 0) return;
+  const int grid = grid_for(nchunks);
+  const float ic = (float)(1.0 / count);
+  if (dtype == kF32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
+                       (const float*)x, (const float*)y, (float*)dx, (float*)dres, nchunks, C / vec, mean,
+                       invstd, gamma, dgamma, dbeta, ic, relu);
+  else if (dtype == kBF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)dx, (bf16_t*)dres, nchunks, C / vec, mean,
+                       invstd, gamma, dgamma, dbeta, ic, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)dy,
+                       (const f16_t*)x, (const f16_t*)y, (f16_t*)dx, (f16_t*)dres, nchunks, C / vec, mean,
+                       invstd, gamma, dgamma, dbeta, ic, relu);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace dpa

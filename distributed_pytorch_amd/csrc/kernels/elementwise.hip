@@ -1,0 +1,252 @@
+// Memory-bound elementwise / layout kernels (gfx950): input normalisation, ReLU, residual add,
+// dropout, casts, weight transposes.  All activation kernels move 16 bytes per lane.
+// Replaces the ATen elementwise kernels and the DataPrefetcher's `.float().sub_().div_()`
+// (reference imagenet_ddp_apex.py:339-340) -- SURVEY.md N-K15..N-K19.
+#include "../common.h"
+#include "kernels.h"
+
+namespace dpa {
+namespace {
+
+inline int grid_for(long n, int per_block = 256) {
+  long b = (n + per_block - 1) / per_block;
+  if (b > 256 * 16) b = 256 * 16;
+  return (int)(b < 1 ? 1 : b);
+}
+
+// uint8 [npix][cin] (NHWC) or [N][cin][hw] (NCHW) -> T [npix][cout], channels >= cin zero padded
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ x, T* __restrict__ y, long npix,
+                                                           int cin, int cout, int hw, int nchw,
+                                                           const float* __restrict__ mean255,
+                                                           const float* __restrict__ inv_std255) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int chunks = cout / VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix * chunks; i += stride) {
+    const long pix = i / chunks;
+    const int c0 = (int)(i - pix * chunks) * VEC;
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      float v = 0.f;
+      if (c < cin) {
+        const uint8_t b = nchw ? x[((pix / hw) * cin + c) * (long)hw + pix % hw] : x[pix * cin + c];
+        v = ((float)b - mean255[c]) * inv_std255[c];
+      }
+      o.set(j, v);
+    }
+    o.store(y + i * VEC);
+  }
+}
+
+// float-ish NCHW -> NHWC with channel padding (LDS-free: C is tiny (3) for images)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y, int NB, int C,
+                                                           int HW, int cpad) {
+  const long total = (long)NB * HW * cpad;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpad);
+    const long pix = i / cpad;
+    const long n = pix / HW, p = pix % HW;
+    y[i] = from_float<TO>(c < C ? to_float(x[(n * C + c) * HW + p]) : 0.f);
+  }
+}
+
+template <typename T, int OP>  // 0: relu, 1: relu_bwd(y, dy), 2: add_relu(a, b)
+__global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                 long nchunks) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+    Vec16<T> va, vb, vo;
+    va.load(a + i * VEC);
+    if (OP != 0) vb.load(b + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float r;
+      if (OP == 0) r = fmaxf(va.get(j), 0.f);
+      else if (OP == 1) r = va.get(j) > 0.f ? vb.get(j) : 0.f;
+      else r = fmaxf(va.get(j) + vb.get(j), 0.f);
+      vo.set(j, r);
+    }
+    vo.store(y + i * VEC);
+  }
+}
+template <typename T, int OP>
+__global__ void ew_tail_kernel(const T* a, const T* b, T* y, long begin, long n) {
+  const long i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  if (OP == 0) r = fmaxf(to_float(a[i]), 0.f);
+  else if (OP == 1) r = to_float(a[i]) > 0.f ? to_float(b[i]) : 0.f;
+  else r = fmaxf(to_float(a[i]) + to_float(b[i]), 0.f);
+  y[i] = from_float<T>(r);
+}
+
+template <typename T, int OP>
+void ew_launch(const void* a, const void* b, void* y, long n, hipStream_t s) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long nchunks = n / VEC;
+  if (nchunks > 0)
+    hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid_for(nchunks)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)y,
+                       nchunks);
+  const long rem = n - nchunks * VEC;
+  if (rem > 0)
+    hipLaunchKernelGGL((ew_tail_kernel<T, OP>), dim3(1), dim3(64), 0, s, (const T*)a, (const T*)b, (T*)y,
+                       nchunks * VEC, n);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+// counter-based RNG (splitmix64 finaliser over (seed, offset + index)): stateless, graph-replayable
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ mask, long n, float p, uint64_t seed,
+                                                          uint64_t offset) {
+  const float scale = 1.f / (1.f - p);
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool keep = hash_u32(seed, offset + (uint64_t)i) >= thr;
+    mask[i] = keep ? 1 : 0;
+    y[i] = from_float<T>(keep ? to_float(x[i]) * scale : 0.f);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                          T* __restrict__ dx, long n, float p) {
+  const float scale = 1.f / (1.f - p);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dx[i] = from_float<T>(mask[i] ? to_float(dy[i]) * scale : 0.f);
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j < n) y[i + j] = from_float<TO>(to_float(x[i + j]));
+  }
+}
+
+// [K][T][C] -> [C][T][K]; 32x32 LDS tile transpose over (K, C) per tap
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_ktc_kernel(const TI* __restrict__ w, TO* __restrict__ wt, int K, int T,
+                                                            int C) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, c = c0 + tx;
+    tile[r][tx] = (k < K && c < C) ? to_float(w[((size_t)k * T + t) * C + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, k = k0 + tx;
+    if (c < C && k < K) wt[((size_t)c * T + t) * K + k] = from_float<TO>(tile[tx][r]);
+  }
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void axpby_kernel(const TX* __restrict__ x, float* __restrict__ y, long n, float alpha,
+                                                    float beta) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = alpha * to_float(x[i]);
+    y[i] = beta == 0.f ? v : v + beta * y[i];
+  }
+}
+
+#define DPA_DISPATCH_2(di, dout, ...)                                                        \
+  DPA_DISPATCH_DTYPE(di, { using TI = T; DPA_DISPATCH_DTYPE(dout, { using TO = T; __VA_ARGS__; }) })
+
+}  // namespace
+
+void normalize_u8_launch(const uint8_t* x, void* y, long npix, int cin, int cout, int hw, int nchw,
+                         const float* mean255, const float* inv_std255, int dtype, hipStream_t s) {
+  if (cout % (dtype == kF32 ? 4 : 8) != 0) throw std::invalid_argument("normalize_u8: cout must fill 16-byte vectors");
+  if (npix <= 0) return;
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(normalize_u8_kernel<T>, dim3(grid_for(npix * (cout / (16 / (int)sizeof(T))))),
+                                               dim3(256), 0, s, x, (T*)y, npix, cin, cout, hw, nchw, mean255,
+                                               inv_std255));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad, int in_dtype, int out_dtype,
+                         hipStream_t s) {
+  const long total = (long)NB * HW * cpad;
+  if (total <= 0) return;
+  DPA_DISPATCH_2(in_dtype, out_dtype,
+                 hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, s,
+                                    (const TI*)x, (TO*)y, NB, C, HW, cpad));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s) {
+  DPA_DISPATCH_DTYPE(dtype, (ew_launch<T, 0>(x, nullptr, y, n, s)));
+}
+void relu_bwd_launch(const void* yv, const void* dy, void* dx, long n, int dtype, hipStream_t s) {
+  DPA_DISPATCH_DTYPE(dtype, (ew_launch<T, 1>(yv, dy, dx, n, s)));
+}
+void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s) {
+  DPA_DISPATCH_DTYPE(dtype, (ew_launch<T, 2>(a, b, y, n, s)));
+}
+
+void dropout_fwd_launch(const void* x, void* y, uint8_t* mask, long n, float p, uint64_t seed, uint64_t offset,
+                        int dtype, hipStream_t s) {
+  if (n <= 0) return;
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(dropout_fwd_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x,
+                                               (T*)y, mask, n, p, seed, offset));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+void dropout_bwd_launch(const void* dy, const uint8_t* mask, void* dx, long n, float p, int dtype, hipStream_t s) {
+  if (n <= 0) return;
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(dropout_bwd_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)dy,
+                                               mask, (T*)dx, n, p));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void cast_launch(const void* x, int in_dtype, void* y, int out_dtype, long n, hipStream_t s) {
+  if (n <= 0) return;
+  DPA_DISPATCH_2(in_dtype, out_dtype,
+                 hipLaunchKernelGGL((cast_kernel<TI, TO>), dim3(grid_for(n, 1024)), dim3(256), 0, s, (const TI*)x,
+                                    (TO*)y, n));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void transpose_ktc_launch(const void* w, void* wt, int K, int ntaps, int C, int in_dtype, int out_dtype,
+                          hipStream_t s) {
+  if (K <= 0 || ntaps <= 0 || C <= 0) return;
+  if (ntaps > 65535) throw std::invalid_argument("transpose_ktc: too many taps");
+  dim3 grid(ceil_div(C, 32), ceil_div(K, 32), ntaps);
+  DPA_DISPATCH_2(in_dtype, out_dtype,
+                 hipLaunchKernelGGL((transpose_ktc_kernel<TI, TO>), grid, dim3(256), 0, s, (const TI*)w, (TO*)wt, K,
+                                    ntaps, C));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void axpby_launch(const void* x, int x_dtype, float* y, long n, float alpha, float beta, hipStream_t s) {
+  if (n <= 0) return;
+  DPA_DISPATCH_DTYPE(x_dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, y, n,
+                                                 alpha, beta));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void fill_launch(void* p, long nbytes, int value, hipStream_t s) {
+  if (nbytes > 0) DPA_CHECK_HIP(hipMemsetAsync(p, value, (size_t)nbytes, s));
+}
+
+}  // namespace dpa

@@ -1,0 +1,128 @@
+// Host-side launch API of the gfx950 kernel library (raw device pointers + hipStream_t).
+// Python reaches these through csrc/bind.cpp; nothing here depends on torch.
+#pragma once
+#include "../common.h"
+
+namespace dpa {
+
+// ------------------------------------------------------------------------------ igemm.hip
+enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2 };
+
+struct IgemmParams {
+  const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
+  const void* B;       // weights [N][ldb], reduction axis contiguous
+  void* C;             // output rows of ldc elements
+  const float* bias;   // optional [N]
+  float* stats;        // optional per-channel partial (sum, sum^2) slab [tiles_m][2][N]
+  const int* taps;     // device int32 triples (dy, dx, wtap), ntaps entries
+  int M, N, Cred, ntaps;
+  int lda, ldb, ldc;
+  int IH, IW;          // gathered image extent
+  int SY, SX;          // gathered-coordinate step per output-grid step
+  int OHF, OWF, OSY, OSX, OY0, OX0;  // scatter of the (sub)grid into the full output (kIgemmScatter)
+  int flags;
+  FastDiv div_ohow, div_ow;          // (sub)grid OH*OW and OW
+};
+void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
+int igemm_tile_m(int dtype);
+
+// ------------------------------------------------------------------------------ wgrad.hip
+struct WgradParams {
+  const void* dY;      // [M][ldy]  output gradient rows (pixels of the OH x OW grid)
+  const void* X;       // NHWC input [NB, IH, IW, ldx]
+  float* slab;         // fp32 partials [splits][N][Ktot]   (N = out channels, Ktot = ntaps*Cred)
+  const int* taps;     // (dy, dx, wtap) triples
+  int M, N, Cred, ntaps, Ktot;
+  int ldy, ldx;
+  int IH, IW, SY, SX;
+  int splits, pix_per_split;
+  FastDiv div_ohow, div_ow;
+};
+void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);
+// out[i] = beta*out[i] + sum_s slab[s][i]   (out dtype f32/bf16/f16), optional column sums
+void slab_reduce_launch(const float* slab, int splits, long n, void* out, int out_dtype, float beta,
+                        hipStream_t stream);
+int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split);
+
+// ------------------------------------------------------------------------------ bn.hip
+// x, y, residual, dy, dx: [M][C] (NHWC flattened), stats fp32.
+int bn_partial_rows(long M, int C);
+void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, int nblk, hipStream_t s);
+// partial: [nparts][2][C] (sum, sumsq) over `count` rows total -> mean, invstd, scale/shift, running update
+void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, long* num_batches_tracked, float* mean, float* invstd,
+                        float* scale, float* shift, hipStream_t s);
+void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, int C, float* scale, float* shift,
+                           hipStream_t s);
+void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
+                     const float* scale, const float* shift, int relu, hipStream_t s);
+// backward: dy masked by (y > 0) when relu; partial [nblk][2][C] = (sum dy, sum dy*xhat)
+void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, int C, int dtype,
+                          const float* mean, const float* invstd, int relu, float* partial, int nblk,
+                          hipStream_t s);
+// sums partials -> dgamma, dbeta (fp32 [C]) and the two per-channel means used by the apply pass
+void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
+                            hipStream_t s);
+void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
+                         int C, int dtype, const float* mean, const float* invstd,
+                         const float* gamma, const float* dgamma, const float* dbeta, double count,
+                         int relu, hipStream_t s);
+
+// ------------------------------------------------------------------------------ pool.hip
+void maxpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,
+                        int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
+void maxpool_bwd_launch(const void* x, const void* dy, void* dx, int NB, int IH, int IW, int C,
+                        int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
+                        hipStream_t s);
+void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,
+                        int dtype, hipStream_t s);
+void avgpool_bwd_launch(const void* dy, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
+                        int dtype, hipStream_t s);
+
+// ------------------------------------------------------------------------------ loss.hip
+// logits [N][C] (dtype), target int64; loss_sum[0] += mean loss contributions; dlogits optional.
+// rowbuf: fp32 workspace [3][N]; metrics (optional): {loss_sum, correct@1, correct@5, rows} accumulated
+void xent_fwd_bwd_launch(const void* logits, const long* target, int N, int C, int ldl, int dtype,
+                         float* loss_out, void* dlogits, float* rowbuf, float* metrics, hipStream_t s);
+void xent_bwd_scale_launch(void* dlogits, long n, int dtype, const float* gout, hipStream_t s);
+
+// ------------------------------------------------------------------------------ elementwise.hip
+void normalize_u8_launch(const uint8_t* x, void* y, long npix, int cin, int cout, int hw, int nchw,
+                         const float* mean255, const float* inv_std255, int dtype, hipStream_t s);
+void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad, int in_dtype,
+                         int out_dtype, hipStream_t s);
+void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
+void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
+void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
+void dropout_fwd_launch(const void* x, void* y, uint8_t* mask, long n, float p, uint64_t seed,
+                        uint64_t offset, int dtype, hipStream_t s);
+void dropout_bwd_launch(const void* dy, const uint8_t* mask, void* dx, long n, float p, int dtype,
+                        hipStream_t s);
+void cast_launch(const void* x, int in_dtype, void* y, int out_dtype, long n, hipStream_t s);
+// [K][T][C] -> [C][T][K]  (conv weight KRSC -> dgrad operand CRSK); cpad zero-pads C of the source view
+void transpose_ktc_launch(const void* w, void* wt, int K, int T, int C, int in_dtype, int out_dtype,
+                          hipStream_t s);
+void axpby_launch(const void* x, int x_dtype, float* y, long n, float alpha, float beta, hipStream_t s);
+void fill_launch(void* p, long nbytes, int value, hipStream_t s);
+
+// ------------------------------------------------------------------------------ optim.hip
+struct SgdTensor {   // one entry per parameter tensor (device table)
+  float* p;          // fp32 master / parameter
+  const void* g;     // gradient (g_dtype)
+  float* buf;        // momentum buffer
+  void* lp;          // optional low-precision copy (lp_dtype) or nullptr
+  long n;
+  long chunk0;       // first chunk index of this tensor in the flattened chunk space
+};
+void sgd_multi_tensor_launch(const SgdTensor* table, int ntensors, long total_chunks, int g_dtype,
+                             int lp_dtype, const float* hyper /*lr, momentum, wd, dampening, nesterov, first*/,
+                             const float* inv_scale, const float* found_inf, hipStream_t s);
+int sgd_chunk_elems();
+void check_finite_flat_launch(const void* g, long n, int dtype, float* found_inf, hipStream_t s);
+void scaler_update_launch(float* scale, float* inv_scale, int* good_steps, float* found_inf,
+                          int growth_interval, float growth, float backoff, float max_scale,
+                          float min_scale, hipStream_t s);
+
+}  // namespace dpa

@@ -1,0 +1,314 @@
+// Weight-gradient implicit GEMM on gfx950 MFMA:
+//
+//     dW[n][t*Cred + c] = sum_m dY[m][n] * X[pix(m) + tap_t][c]
+//
+// The reduction axis (pixels, up to millions) is the slow memory axis of BOTH operands, so the
+// tiles are staged pixel-major in LDS ([pixel][channel], exactly as they sit in HBM) and the MFMA
+// fragments are fetched with the gfx950 transposed LDS read (ds_read_b64_tr_b16): no explicit
+// transpose anywhere.  fp32 uses the 32x32x2 f32 MFMA whose one-element-per-lane operands read
+// the pixel-major tile directly.
+//
+// The pixel range is split across workgroups; each writes an fp32 partial slab and a second
+// kernel sums the slabs in a fixed order (deterministic, no float atomics) straight into the
+// parameter's gradient (which may be a view into a DDP bucket).
+//
+// Replaces cuDNN's backward-filter + cuBLAS dW GEMMs (reference: loss.backward() at
+// nd_imagenet.py:302, imagenet_ddp_apex.py:381) -- SURVEY.md N-K3, N-K10.
+#include "../common.h"
+#include "kernels.h"
+#include <stdexcept>
+#include <string>
+
+namespace dpa {
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+__device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  uint2 r;
+  __builtin_memcpy(&r, &v, 8);
+  return r;
+}
+
+template <typename T, int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BKP = 64 / (int)sizeof(T);             // pixels per K tile (64 bytes of K per column)
+  constexpr int LDP = BI * (int)sizeof(T) + 64;        // row stride = 64 (mod 128): conflict-free tr reads
+  constexpr int LDQ = BJ * (int)sizeof(T) + 64;
+  constexpr int CPP = BI * (int)sizeof(T) / 16, CPQ = BJ * (int)sizeof(T) / 16;
+  constexpr int P_IT = BKP * CPP / 256, Q_IT = BKP * CPQ / 256;
+  constexpr int WTI = BI / 2, WTJ = BJ / 2;
+  constexpr int MI = WTI / 32, NJ = WTJ / 32;
+  constexpr int STAGE = BKP * (LDP + LDQ);
+  static_assert(P_IT >= 1 && Q_IT >= 1 && MI >= 1 && NJ >= 1, "tile too small");
+  static_assert(256 % CPP == 0 && 256 % CPQ == 0, "chunk mapping");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+
+  const uint32_t tiles_i = (p.N + BI - 1) / BI, tiles_j = (p.Ktot + BJ - 1) / BJ;
+  const uint32_t tiles = tiles_i * tiles_j;
+  const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t split = lid / tiles, tile = lid - split * tiles;
+  const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+  const int i0 = ti * BI, j0 = tj * BJ;
+
+  const int m_begin = split * p.pix_per_split;
+  const int m_end = min(p.M, m_begin + p.pix_per_split);
+
+  const char* __restrict__ Yg = reinterpret_cast<const char*>(p.dY);
+  const char* __restrict__ Xg = reinterpret_cast<const char*>(p.X);
+
+  // fixed per-thread columns
+  const int cp = tid % CPP;                   // dY chunk column
+  const bool pok = i0 + cp * VEC < p.N;       // N is a multiple of VEC
+  const int cq = tid % CPQ;                   // im2col chunk column
+  const int kcol = j0 + cq * VEC;
+  const bool qok = kcol < p.Ktot;
+  int qdy = 0, qdx = 0, qc = 0;
+  if (qok) {
+    const int t = kcol / p.Cred;
+    qc = kcol - t * p.Cred;
+    qdy = p.taps[3 * t + 0];
+    qdx = p.taps[3 * t + 1];
+  }
+
+  uint4 rp[P_IT], rq[Q_IT];
+  auto load_tile = [&](int m_base) {
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int row = (tid + i * 256) / CPP;
+      const int m = m_base + row;
+      const bool ok = pok && m < m_end;
+      rp[i] = ok ? *reinterpret_cast<const uint4*>(Yg + ((size_t)m * p.ldy + i0 + cp * VEC) * sizeof(T))
+                 : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < Q_IT; ++i) {
+      const int row = (tid + i * 256) / CPQ;
+      const uint32_t m = m_base + row;
+      bool ok = qok && (int)m < m_end;
+      size_t off = 0;
+      if (ok) {
+        const uint32_t n = fdiv(m, p.div_ohow);
+        const uint32_t rem = m - n * p.div_ohow.d;
+        const uint32_t oy = fdiv(rem, p.div_ow);
+        const uint32_t ox = rem - oy * p.div_ow.d;
+        const int iy = (int)oy * p.SY + qdy, ix = (int)ox * p.SX + qdx;
+        ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        off = ((size_t)((int)n * p.IH * p.IW + iy * p.IW + ix) * p.ldx + qc) * sizeof(T);
+      }
+      rq[i] = ok ? *reinterpret_cast<const uint4*>(Xg + off) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sp = smem + buf * STAGE;
+    unsigned char* sq = sp + BKP * LDP;
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int row = (tid + i * 256) / CPP;
+      *reinterpret_cast<uint4*>(sp + row * LDP + cp * 16) = rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < Q_IT; ++i) {
+      const int row = (tid + i * 256) / CPQ;
+      *reinterpret_cast<uint4*>(sq + row * LDQ + cq * 16) = rq[i];
+    }
+  };
+
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (m_end - m_begin + BKP - 1) / BKP;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int g = lane >> 4, gi = lane & 15;
+
+  if (nk > 0) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(m_begin + (kt + 1) * BKP);
+    const unsigned char* sp = smem + cur * STAGE;
+    const unsigned char* sq = sp + BKP * LDP;
+    if constexpr (sizeof(T) == 2) {
+      // lane address inside a 4-row x 16-col transposed block; see cdna guide T10
+      const int trow = 8 * (g >> 1) + (gi >> 2);
+      const int tcol = 16 * (g & 1) + 4 * (gi & 3);
+#pragma unroll
+      for (int ks = 0; ks < BKP / 16; ++ks) {
+        uint4 af[MI], bf[NJ];
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+          const unsigned char* base = sp + (ks * 16 + trow) * LDP + (wi * WTI + a * 32 + tcol) * 2;
+          const uint2 lo = tr_read(base), hi = tr_read(base + 4 * LDP);
+          af[a] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) {
+          const unsigned char* base = sq + (ks * 16 + trow) * LDQ + (wj * WTJ + b * 32 + tcol) * 2;
+          const uint2 lo = tr_read(base), hi = tr_read(base + 4 * LDQ);
+          bf[b] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+          for (int b = 0; b < NJ; ++b) {
+            if constexpr (TypeInfo<T>::kCode == kBF16) {
+              bf16x8_t av, bv;
+              __builtin_memcpy(&av, &af[a], 16);
+              __builtin_memcpy(&bv, &bf[b], 16);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[a][b], 0, 0, 0);
+            } else {
+              f16x8_t av, bv;
+              __builtin_memcpy(&av, &af[a], 16);
+              __builtin_memcpy(&bv, &bf[b], 16);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[a][b], 0, 0, 0);
+            }
+          }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BKP / 2; ++ks) {
+        float af[MI], bf[NJ];
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+          af[a] = *reinterpret_cast<const float*>(sp + (2 * ks + lh) * LDP + (wi * WTI + a * 32 + l31) * 4);
+#pragma unroll
+        for (int b = 0; b < NJ; ++b)
+          bf[b] = *reinterpret_cast<const float*>(sq + (2 * ks + lh) * LDQ + (wj * WTJ + b * 32 + l31) * 4);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+          for (int b = 0; b < NJ; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // acc[a][b][r]: i = wi*WTI + a*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wj*WTJ + b*32 + l31
+  float* __restrict__ out = p.slab + (size_t)split * p.N * p.Ktot;
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NJ; ++b) {
+      const int j = j0 + wj * WTJ + b * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * WTI + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (i < p.N && j < p.Ktot) out[(size_t)i * p.Ktot + j] = acc[a][b][r];
+      }
+    }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, long n,
+                                                          TO* __restrict__ out, float beta) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      float4 s = *reinterpret_cast<const float4*>(slab + i);
+      for (int k = 1; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)k * n + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float r[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float o = r[j];
+        if (beta != 0.f) o += beta * to_float(out[i + j]);
+        out[i + j] = from_float<TO>(o);
+      }
+    } else {
+      for (long e = i; e < n; ++e) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + e];
+        if (beta != 0.f) s += beta * to_float(out[e]);
+        out[e] = from_float<TO>(s);
+      }
+    }
+  }
+}
+
+template <typename T, int BI, int BJ>
+void launch_cfg(const WgradParams& p, hipStream_t stream) {
+  constexpr int BKP = 64 / (int)sizeof(T);
+  constexpr int lds = 2 * BKP * ((BI + BJ) * (int)sizeof(T) + 128);
+  const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
+  hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+}
+
+template <typename T>
+void dispatch(const WgradParams& p, hipStream_t stream) {
+  if (p.N > 64 && p.Ktot > 64) launch_cfg<T, 128, 128>(p, stream);
+  else launch_cfg<T, 64, 64>(p, stream);
+}
+
+}  // namespace
+
+int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split) {
+  const int bkp = dtype == kF32 ? 16 : 32;
+  const int tile = (N > 64 && Ktot > 64) ? 128 : 64;
+  const long tiles = (long)ceil_div(N, tile) * ceil_div(Ktot, tile);
+  // aim for ~3 workgroups per CU, keep >= 8 K tiles per workgroup, and bound the slab size
+  long splits = (768 + tiles - 1) / tiles;
+  const long max_by_work = (M + 8l * bkp - 1) / (8l * bkp);
+  if (splits > max_by_work) splits = max_by_work;
+  const long out_elems = (long)N * Ktot;
+  const long max_by_slab = (64l << 20) / (out_elems * 4) + 1;   // <= ~64 MiB of partials
+  if (splits > max_by_slab) splits = max_by_slab;
+  if (splits < 1) splits = 1;
+  long pps = (M + splits - 1) / splits;
+  pps = (pps + bkp - 1) / bkp * bkp;
+  splits = (M + pps - 1) / pps;
+  *pix_per_split = (int)pps;
+  return (int)splits;
+}
+
+void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+  const int vec = dtype == kF32 ? 4 : 8;
+  if (p.M <= 0 || p.N <= 0 || p.Ktot <= 0) return;
+  if (p.N % vec != 0 || p.Cred % vec != 0 || p.ldy % vec != 0 || p.ldx % vec != 0)
+    throw std::invalid_argument("wgrad: channel counts / strides must be multiples of 16 bytes");
+  if (p.Ktot != p.ntaps * p.Cred) throw std::invalid_argument("wgrad: Ktot != ntaps*Cred");
+  if ((long)p.splits * p.pix_per_split < p.M) throw std::invalid_argument("wgrad: splits do not cover M");
+  if (dtype == kF32) dispatch<float>(p, stream);
+  else if (dtype == kBF16) dispatch<bf16_t>(p, stream);
+  else if (dtype == kF16) dispatch<f16_t>(p, stream);
+  else throw std::invalid_argument("wgrad: unsupported dtype");
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void slab_reduce_launch(const float* slab, int splits, long n, void* out, int out_dtype, float beta,
+                        hipStream_t stream) {
+  if (n <= 0) return;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (out_dtype == kF32)
+    hipLaunchKernelGGL(slab_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, slab, splits, n,
+                       reinterpret_cast<float*>(out), beta);
+  else if (out_dtype == kBF16)
+    hipLaunchKernelGGL(slab_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, slab, splits, n,
+                       reinterpret_cast<bf16_t*>(out), beta);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, slab, splits, n,
+                       reinterpret_cast<f16_t*>(out), beta);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace dpa

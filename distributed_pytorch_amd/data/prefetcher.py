@@ -1,0 +1,71 @@
+"""StreamPrefetcher — async H2D + on-GPU normalise on a side HIP stream.
+
+Same contract as the reference ``DataPrefetcher`` (``imagenet_ddp_apex.py:304-351``):
+``next()`` returns the already-resident, already-normalised batch, makes the
+compute stream wait on the copy stream, ``record_stream``s both tensors and
+immediately starts the following batch.  Differences, by design:
+
+* the uint8 batch is normalised by ONE fused HIP kernel (``u8_nhwc_to_norm``,
+  N-K16) straight into the compute dtype and the 8-channel-padded NHWC layout the
+  stem convolution consumes — not ``.float().sub_().div_()`` (3 passes);
+* works on CPU too (no streams) so the loops are testable without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..ops import functional as F
+
+
+class StreamPrefetcher:
+    def __init__(self, loader, device: torch.device, dtype: torch.dtype = torch.float32,
+                 pad_c: int = 0, normalize: bool = True):
+        self.loader = iter(loader)
+        self.device, self.dtype, self.pad_c, self.normalize = device, dtype, pad_c, normalize
+        self.on_gpu = device.type == "cuda"
+        self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device) if self.on_gpu else None
+        self.next_input = None
+        self.next_target = None
+        self.preload()
+
+    def _stage(self, images: torch.Tensor, target: torch.Tensor):
+        images = images.to(self.device, non_blocking=True)
+        target = target.to(self.device, non_blocking=True)
+        if images.dtype == torch.uint8 and self.normalize:
+            layout = "nhwc" if images.shape[-1] in (1, 3) else "nchw"
+            images = F.normalize_u8(images, self.dtype, self.pad_c, input_layout=layout)
+            images._dpa_nhwc = True
+        return images, target
+
+    def preload(self) -> None:
+        try:
+            images, target = next(self.loader)
+        except StopIteration:
+            self.next_input = self.next_target = None
+            return
+        if self.on_gpu:
+            with torch.cuda.stream(self.stream):
+                self.next_input, self.next_target = self._stage(images, target)
+        else:
+            self.next_input, self.next_target = self._stage(images, target)
+
+    def next(self):
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        images, target = self.next_input, self.next_target
+        if self.on_gpu:
+            if images is not None:
+                images.record_stream(torch.cuda.current_stream(self.device))
+            if target is not None:
+                target.record_stream(torch.cuda.current_stream(self.device))
+        self.preload()
+        return images, target
+
+    def __iter__(self):
+        while True:
+            images, target = self.next()
+            if images is None:
+                return
+            yield images, target

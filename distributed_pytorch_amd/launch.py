@@ -1,0 +1,174 @@
+"""Process topology: one process per GPU, supervised.
+
+Covers the launcher layer of the reference — ``mp.spawn(main_worker, nprocs=ngpus)``
+(``nd_imagenet.py:103-113``, ``imagenet_ddp.py:72-86``), the
+``torch.distributed.launch`` contract of the AMP script (``--local_rank`` +
+``WORLD_SIZE``/``RANK`` env, ``imagenet_ddp_apex.py:88,113-129``) and the
+rendezvous (``dist.init_process_group(backend, init_method, world_size, rank)``,
+``imagenet_ddp.py:103-105``; global rank = ``node_rank * ngpus + gpu``).
+
+Additions the reference lacks: a supervisor that tears every
+rank down as soon as one dies (the reference needs ``process_cleanup.sh``), a
+rendezvous/collective timeout instead of blocking forever, NUMA-friendly CPU
+affinity per local rank, and a ``--fault-inject RANK:STEP`` hook for tests.
+"""
+from __future__ import annotations
+
+import datetime
+import multiprocessing as mp
+import os
+import signal
+import sys
+import time
+import traceback
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def device_count() -> int:
+    """GPUs on this node; ``DPA_NPROC_PER_NODE`` overrides (CPU/gloo tests)."""
+    env = os.environ.get("DPA_NPROC_PER_NODE")
+    if env:
+        return int(env)
+    return torch.cuda.device_count()
+
+
+def resolve_backend(name: str, use_gpu: bool) -> str:
+    name = (name or "nccl").lower()
+    if name == "rccl":
+        name = "nccl"
+    if name == "nccl" and not use_gpu:
+        return "gloo"          # CPU plumbing configuration (BASELINE config #1)
+    return name
+
+
+def parse_dist_url(url: str) -> Tuple[str, Optional[str], Optional[int]]:
+    """-> (scheme, host, port) for ``tcp://host:port`` / ``env://`` / ``file://path``."""
+    if url.startswith("env://"):
+        return "env", os.environ.get("MASTER_ADDR"), \
+            int(os.environ["MASTER_PORT"]) if "MASTER_PORT" in os.environ else None
+    if url.startswith("tcp://"):
+        host, _, port = url[len("tcp://"):].rpartition(":")
+        return "tcp", host, int(port)
+    if url.startswith("file://"):
+        return "file", url[len("file://"):], None
+    raise ValueError("unsupported --dist-url %r" % url)
+
+
+def global_rank(node_rank: int, ngpus_per_node: int, local_rank: int) -> int:
+    return node_rank * ngpus_per_node + local_rank
+
+
+def set_affinity(local_rank: int, nprocs: int) -> None:
+    """Give each rank a contiguous slice of the CPUs this process may use."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        share = max(1, len(cpus) // max(1, nprocs))
+        mine = cpus[local_rank * share:(local_rank + 1) * share] or cpus
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+    except (AttributeError, OSError):
+        pass
+
+
+def init_process_group(backend: str, init_method: str, world_size: int, rank: int,
+                       timeout_s: float = 600.0, use_gpu: bool = True) -> None:
+    backend = resolve_backend(backend, use_gpu)
+    kwargs = dict(backend=backend, init_method=init_method, world_size=world_size, rank=rank,
+                  timeout=datetime.timedelta(seconds=timeout_s))
+    if backend == "nccl" and use_gpu:
+        try:
+            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        except Exception:  # noqa: BLE001
+            pass
+    dist.init_process_group(**kwargs)
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ----------------------------------------------------------------------------- supervisor
+def _child(fn: Callable, local_rank: int, nprocs: int, args: tuple, err_q) -> None:
+    os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    set_affinity(local_rank, nprocs)
+    try:
+        fn(local_rank, *args)
+    except KeyboardInterrupt:
+        sys.exit(130)
+    except SystemExit:
+        raise
+    except BaseException:  # noqa: BLE001
+        err_q.put((local_rank, traceback.format_exc()))
+        sys.exit(1)
+
+
+class ProcessFailure(RuntimeError):
+    def __init__(self, local_rank: int, exitcode: int, tb: str = ""):
+        super().__init__("rank-local process %d failed with exit code %s\n%s"
+                         % (local_rank, exitcode, tb))
+        self.local_rank, self.exitcode, self.tb = local_rank, exitcode, tb
+
+
+def spawn(fn: Callable, nprocs: int, args: tuple = (), poll_s: float = 0.2,
+          grace_s: float = 5.0) -> None:
+    """Run ``fn(local_rank, *args)`` in ``nprocs`` fresh processes (spawn context,
+    so no GPU state is inherited).  First failure => SIGTERM, then SIGKILL, to all
+    siblings, and a ``ProcessFailure`` carrying the child's traceback."""
+    ctx = mp.get_context("spawn")
+    err_q = ctx.SimpleQueue()
+    procs = []
+    for lr in range(nprocs):
+        p = ctx.Process(target=_child, args=(fn, lr, nprocs, args, err_q), daemon=False)
+        p.start()
+        procs.append(p)
+    failed: Optional[Tuple[int, int]] = None
+    try:
+        alive = set(range(nprocs))
+        while alive and failed is None:
+            for i in list(alive):
+                p = procs[i]
+                if p.exitcode is not None:
+                    alive.discard(i)
+                    if p.exitcode != 0:
+                        failed = (i, p.exitcode)
+                        break
+            if alive and failed is None:
+                time.sleep(poll_s)
+    except KeyboardInterrupt:
+        failed = (-1, 130)
+    finally:
+        if failed is not None:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            deadline = time.time() + grace_s
+            for p in procs:
+                p.join(max(0.0, deadline - time.time()))
+            for p in procs:
+                if p.is_alive():
+                    os.kill(p.pid, signal.SIGKILL)
+                    p.join(1.0)
+    if failed is not None:
+        tb = ""
+        while not err_q.empty():
+            lr, text = err_q.get()
+            if lr == failed[0] or not tb:
+                tb = text
+        raise ProcessFailure(failed[0], failed[1], tb)
+
+
+def maybe_fault_inject(spec: Optional[str], rank: int, step: int) -> None:
+    """``--fault-inject RANK:STEP``: die hard (no cleanup) to exercise the supervisor."""
+    if not spec:
+        return
+    r, _, s = spec.partition(":")
+    if int(r) == rank and int(s) == step:
+        os._exit(17)

@@ -1,0 +1,176 @@
+"""NHWC neural-network modules with torchvision-compatible parameter names.
+
+Parameters keep torch's *logical* shapes (conv ``[K, C, R, S]``, linear
+``[out, in]``) so ``state_dict()`` is interchangeable with checkpoints written by
+the reference scripts, but conv weights use the
+``channels_last`` memory format: their bytes are already the KRSC layout the HIP
+implicit-GEMM kernels consume, so no per-step layout conversion exists.
+
+Initialisation follows torchvision (kaiming-normal fan_out for ResNet convs,
+default ``nn.Conv2d``/``nn.Linear`` init elsewhere) so that random-init
+behaviour matches ``models.__dict__[arch]()`` in reference ``nd_imagenet.py:138``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from ..ops import functional as F
+from .. import amp as _amp
+
+
+class Conv2d(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0,
+                 bias: bool = True):
+        super().__init__()
+        k = F._pair(kernel_size)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = k, F._pair(stride), F._pair(padding)
+        w = torch.empty(out_channels, in_channels, k[0], k[1]).contiguous(
+            memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.needs_input_grad = True  # the stem sets this False: no dgrad to the image
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x: torch.Tensor, relu: bool = False, want_stats: bool = False):
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu=relu,
+                        w_lp=_amp.compute_copy(self.weight, x), want_stats=want_stats,
+                        needs_input_grad=self.needs_input_grad)
+
+    def extra_repr(self) -> str:
+        return "{}, {}, kernel_size={}, stride={}, padding={}, bias={}".format(
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+            self.bias is not None)
+
+
+class BatchNorm2d(nn.Module):
+    """BatchNorm over the channel (last) axis with optional fused residual-add and ReLU."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.process_group = None  # set by convert_syncbn_model
+
+    def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
+                stats=None) -> torch.Tensor:
+        return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var,
+                            self.num_batches_tracked, self.training, self.momentum, self.eps,
+                            relu=relu, residual=residual, stats=stats, group=self.process_group)
+
+    def extra_repr(self) -> str:
+        return "{}, eps={}, momentum={}{}".format(self.num_features, self.eps, self.momentum,
+                                                  ", sync" if self.process_group is not None else "")
+
+
+class SyncBatchNorm(BatchNorm2d):
+    """BatchNorm2d whose batch statistics span every rank of ``process_group``
+    (Apex ``convert_syncbn_model`` parity, reference ``imagenet_ddp_apex.py:146-148``)."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1,
+                 process_group="world"):
+        super().__init__(num_features, eps, momentum)
+        self.process_group = process_group
+
+
+class ReLU(nn.Module):
+    def __init__(self, inplace: bool = False):
+        super().__init__()
+
+    def forward(self, x):
+        return F.relu(x)
+
+
+class MaxPool2d(nn.Module):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def forward(self, x):
+        return F.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+
+class AdaptiveAvgPool2d(nn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, x):
+        return F.adaptive_avg_pool2d(x, self.output_size)
+
+
+class Dropout(nn.Module):
+    def __init__(self, p: float = 0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return F.dropout(x, self.p, self.training)
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(self.in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, relu: bool = False, out_dtype=None):
+        return F.linear(x, self.weight, self.bias, relu=relu,
+                        w_lp=_amp.compute_copy(self.weight, x), out_dtype=out_dtype)
+
+    def extra_repr(self) -> str:
+        return "in_features={}, out_features={}, bias={}".format(
+            self.in_features, self.out_features, self.bias is not None)
+
+
+class CrossEntropyLoss(nn.Module):
+    """Mean softmax cross-entropy (reference ``nn.CrossEntropyLoss`` at ``nd_imagenet.py:172``)."""
+
+    def forward(self, logits, target):
+        return F.cross_entropy(logits, target)
+
+
+class Flatten(nn.Module):
+    """Flattens NHWC activations in **NCHW order** so Linear weights stay
+    checkpoint-compatible with torchvision's ``torch.flatten(x, 1)``."""
+
+    def forward(self, x):
+        if x.dim() == 4:
+            if x.shape[1] == 1 and x.shape[2] == 1:
+                return x.reshape(x.shape[0], -1)
+            return x.permute(0, 3, 1, 2).reshape(x.shape[0], -1)
+        return x.reshape(x.shape[0], -1)
+
+
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool = True, residual=None):
+    """conv -> BN(+residual)(+ReLU).  On the GPU the conv epilogue emits the
+    per-channel sum/sumsq partials that BN consumes, so the conv output is not
+    re-read for statistics."""
+    fuse = x.is_cuda and bn.training and bn.process_group is None
+    if fuse:
+        y, stats = conv(x, want_stats=True)
+        return bn(y, relu=relu, residual=residual, stats=stats)
+    return bn(conv(x), relu=relu, residual=residual)

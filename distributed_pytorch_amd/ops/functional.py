@@ -1,0 +1,222 @@
+"""Functional op layer.  Activations are **NHWC** tensors ``[N, H, W, C]``.
+
+Dispatch rule (see ``backend.py``): CPU tensors -> pure PyTorch reference math
+(the oracle for every test and the BASELINE "config #1" plumbing backend);
+GPU tensors -> hand-written HIP kernels in ``csrc/kernels`` through
+``ops/hip_ops.py``.  The op set is the implicit native surface of the reference
+scripts: what cuDNN / cuBLAS / ATen / Apex ran for
+``model(images)``, ``criterion``, ``loss.backward()`` and ``optimizer.step()``
+(reference ``nd_imagenet.py:291-303``, ``imagenet_ddp_apex.py:339-383``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as TF
+
+
+def _on_gpu(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+def _hip():
+    from . import hip_ops
+
+    return hip_ops
+
+
+def _pair(v) -> Tuple[int, int]:
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+# ----------------------------------------------------------------------------- conv
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           stride=1, padding=0, *, relu: bool = False, w_lp: Optional[torch.Tensor] = None,
+           want_stats: bool = False, needs_input_grad: bool = True):
+    """NHWC convolution.  ``weight`` is logical ``[K, C, R, S]`` (memory KRSC).
+
+    ``w_lp``: optional low-precision compute copy of ``weight`` (AMP O1/O2);
+    gradients still flow to ``weight``.  ``want_stats`` additionally returns the
+    per-channel ``(sum, sumsq)`` of the output computed in the conv epilogue
+    (feeds the fused BatchNorm).  ``needs_input_grad=False`` skips dgrad (stem).
+    """
+    stride, padding = _pair(stride), _pair(padding)
+    if _on_gpu(x):
+        return _hip().conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats,
+                             needs_input_grad)
+    w = weight if w_lp is None else _StraightThroughCast.apply(weight, x.dtype)
+    if w.dtype != x.dtype:
+        w = w.to(x.dtype)
+    b = None if bias is None else bias.to(x.dtype)
+    y = TF.conv2d(x.permute(0, 3, 1, 2), w, b, stride, padding).permute(0, 2, 3, 1)
+    if relu:
+        y = TF.relu(y)
+    y = y.contiguous()
+    if want_stats:
+        return y, None
+    return y
+
+
+class _StraightThroughCast(torch.autograd.Function):
+    """fp32 master -> low precision for compute; gradient returns in fp32."""
+
+    @staticmethod
+    def forward(ctx, w, dtype):
+        return w.to(dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float(), None
+
+
+# ----------------------------------------------------------------------------- batch norm
+def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+               running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
+               num_batches_tracked: Optional[torch.Tensor], training: bool,
+               momentum: float = 0.1, eps: float = 1e-5, *, relu: bool = False,
+               residual: Optional[torch.Tensor] = None, stats=None, group=None) -> torch.Tensor:
+    """Fused ``BN [+ residual] [+ ReLU]`` over NHWC (N-K4/K5/K7; SyncBN when
+    ``group`` is a process group: N-K6).  Statistics are always fp32.
+    ``running_var`` receives the unbiased variance, as in torch / cuDNN.
+    """
+    if _on_gpu(x):
+        return _hip().batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked,
+                                 training, momentum, eps, relu, residual, stats, group)
+    if group is not None and training:
+        from ..parallel.sync_batchnorm import sync_batch_norm_reference
+
+        y = sync_batch_norm_reference(x, weight, bias, running_mean, running_var,
+                                      num_batches_tracked, momentum, eps, group)
+    else:
+        xc = x.permute(0, 3, 1, 2)
+        if training and num_batches_tracked is not None:
+            num_batches_tracked.add_(1)
+        y = TF.batch_norm(xc.float(), running_mean, running_var, weight.float(), bias.float(),
+                          training, momentum, eps).to(x.dtype).permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = TF.relu(y)
+    return y.contiguous()
+
+
+# ----------------------------------------------------------------------------- pooling
+def max_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0) -> torch.Tensor:
+    k, s, p = _pair(kernel_size), _pair(stride if stride is not None else kernel_size), _pair(padding)
+    if _on_gpu(x):
+        return _hip().max_pool2d(x, k, s, p)
+    return TF.max_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
+
+
+def adaptive_avg_pool2d(x: torch.Tensor, output_size) -> torch.Tensor:
+    o = _pair(output_size)
+    if _on_gpu(x):
+        return _hip().adaptive_avg_pool2d(x, o)
+    return TF.adaptive_avg_pool2d(x.permute(0, 3, 1, 2), o).permute(0, 2, 3, 1).contiguous()
+
+
+def relu(x: torch.Tensor) -> torch.Tensor:
+    if _on_gpu(x):
+        return _hip().relu(x)
+    return TF.relu(x)
+
+
+def add_relu(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Residual ``relu(x + y)`` (N-K17) when it is not fused into BatchNorm."""
+    if _on_gpu(x):
+        return _hip().add_relu(x, y)
+    return TF.relu(x + y)
+
+
+def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    if not training or p == 0.0:
+        return x
+    if _on_gpu(x):
+        return _hip().dropout(x, p)
+    return TF.dropout(x, p, True)
+
+
+# ----------------------------------------------------------------------------- linear
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+           relu: bool = False, w_lp: Optional[torch.Tensor] = None,
+           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``y = x @ weight.T + bias`` (N-K10), optional fused ReLU epilogue."""
+    if _on_gpu(x):
+        return _hip().linear(x, weight, bias, relu, w_lp, out_dtype)
+    w = weight if w_lp is None else _StraightThroughCast.apply(weight, x.dtype)
+    if w.dtype != x.dtype:
+        w = w.to(x.dtype)
+    y = TF.linear(x, w, None if bias is None else bias.to(x.dtype))
+    if relu:
+        y = TF.relu(y)
+    if out_dtype is not None:
+        y = y.to(out_dtype)
+    return y
+
+
+# ----------------------------------------------------------------------------- loss / metrics
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, loss_scale=None) -> torch.Tensor:
+    """Mean softmax cross-entropy (N-K11).  fp32 math regardless of input dtype."""
+    if _on_gpu(logits):
+        return _hip().cross_entropy(logits, target)
+    return TF.cross_entropy(logits.float(), target)
+
+
+def topk_correct(output: torch.Tensor, target: torch.Tensor, topk: Sequence[int] = (1, 5)) -> torch.Tensor:
+    """Number of rows whose target is within the top-k, float32 ``[len(topk)]`` (N-K12)."""
+    if _on_gpu(output):
+        return _hip().topk_correct(output, target, tuple(topk))
+    z = output.float()
+    zt = z.gather(1, target.view(-1, 1))
+    rank = (z > zt).sum(dim=1)
+    return torch.stack([(rank < k).sum().float() for k in topk])
+
+
+def loss_and_metrics(logits: torch.Tensor, target: torch.Tensor):
+    """-> (mean loss with grad, float32[4] record = loss*n, correct@1, correct@5, n)."""
+    loss = cross_entropy(logits, target)
+    with torch.no_grad():
+        n = float(target.numel())
+        k5 = min(5, logits.shape[1])
+        c = topk_correct(logits, target, (1, k5))
+        rec = torch.stack([loss.detach().float() * n, c[0], c[1],
+                           torch.tensor(n, device=logits.device)])
+    return loss, rec
+
+
+# ----------------------------------------------------------------------------- input pipeline
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_u8(x: torch.Tensor, dtype: torch.dtype = torch.float32, pad_c: int = 0,
+                 mean=IMAGENET_MEAN, std=IMAGENET_STD, input_layout: str = "nhwc") -> torch.Tensor:
+    """uint8 image batch -> normalised NHWC ``dtype`` (N-K16).
+
+    ``(x - 255*mean_c) / (255*std_c)``, identical to the reference prefetcher
+    (``imagenet_ddp_apex.py:311-340``).  ``pad_c`` zero-pads channels 3 -> pad_c
+    so the stem convolution sees a vector-width-aligned C.
+    """
+    if _on_gpu(x):
+        return _hip().normalize_u8(x, dtype, pad_c, mean, std, input_layout)
+    if input_layout == "nchw":
+        x = x.permute(0, 2, 3, 1)
+    m = torch.tensor(mean, dtype=torch.float32) * 255.0
+    s = torch.tensor(std, dtype=torch.float32) * 255.0
+    y = ((x.float() - m) / s).to(dtype)
+    if pad_c and pad_c > y.shape[-1]:
+        y = TF.pad(y, (0, pad_c - y.shape[-1]))
+    return y.contiguous()
+
+
+def to_nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_c: int = 0) -> torch.Tensor:
+    """Float NCHW (torchvision convention) -> NHWC compute layout."""
+    if _on_gpu(x):
+        return _hip().nchw_to_nhwc(x, dtype or x.dtype, pad_c)
+    y = x.permute(0, 2, 3, 1)
+    if dtype is not None:
+        y = y.to(dtype)
+    if pad_c and pad_c > y.shape[-1]:
+        y = TF.pad(y, (0, pad_c - y.shape[-1]))
+    return y.contiguous()

@@ -1,0 +1,99 @@
+"""SyncBatchNorm: batch statistics over every rank of the process group.
+
+Replaces ``apex.parallel.convert_syncbn_model`` (reference
+``imagenet_ddp_apex.py:146-148``).  Forward: local per-channel ``[sum, sumsq, n]``
+(fp32) -> ONE all-reduce of a ``2C+1`` vector -> mean / biased var -> normalise;
+``running_var`` gets the unbiased global variance.  Backward: ONE all-reduce of
+``[sum(dy), sum(dy*xhat)]`` (``2C`` floats), then the usual BN input gradient with
+the global element count (collective inventory C-h / C-i).
+
+This file holds the process-group plumbing and the CPU reference math; on the GPU
+the local reductions and the normalise/backward passes are the HIP kernels
+``syncbn_*`` (same kernels as plain BN, with the cross-rank reduction inserted
+between their reduce and apply phases).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ..nn.modules import BatchNorm2d, SyncBatchNorm
+
+
+def _group(group):
+    return None if group in (None, "world") else group
+
+
+def _world(group) -> int:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(_group(group))
+
+
+def all_reduce_sum_(t: torch.Tensor, group) -> torch.Tensor:
+    if _world(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group(group))
+    return t
+
+
+class _SyncBNFunction(torch.autograd.Function):
+    """Reference (pure torch) SyncBN over NHWC input; used for CPU tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, group):
+        c = x.shape[-1]
+        xf = x.reshape(-1, c).float()
+        packed = torch.cat([xf.sum(0), (xf * xf).sum(0),
+                            torch.tensor([float(xf.shape[0])], device=x.device)])
+        all_reduce_sum_(packed, group)
+        count = packed[-1]
+        mean = packed[:c] / count
+        var = (packed[c:2 * c] / count - mean * mean).clamp_min_(0.0)
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                unbiased = var * (count / (count - 1).clamp_min(1.0))
+                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+                if nbt is not None:
+                    nbt.add_(1)
+        xhat = (xf - mean) * invstd
+        y = (xhat * weight.float() + bias.float()).to(x.dtype).reshape(x.shape)
+        ctx.save_for_backward(xhat, weight, invstd, count)
+        ctx.group = group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, weight, invstd, count = ctx.saved_tensors
+        c = dy.shape[-1]
+        g = dy.reshape(-1, c).float()
+        sums = torch.cat([g.sum(0), (g * xhat).sum(0)])
+        dbias, dweight = sums[:c].clone(), sums[c:].clone()   # local: DDP averages params' grads
+        all_reduce_sum_(sums, ctx.group)
+        mean_dy, mean_dyx = sums[:c] / count, sums[c:] / count
+        dx = (g - mean_dy - xhat * mean_dyx) * (weight.float() * invstd)
+        return (dx.to(dy.dtype).reshape(dy.shape), dweight.to(weight.dtype),
+                dbias.to(weight.dtype), None, None, None, None, None, None)
+
+
+def sync_batch_norm_reference(x, weight, bias, running_mean, running_var, nbt, momentum, eps, group):
+    return _SyncBNFunction.apply(x, weight, bias, running_mean, running_var, nbt, momentum, eps,
+                                 group)
+
+
+def convert_syncbn_model(module: nn.Module, process_group="world") -> nn.Module:
+    """Recursively swaps every ``BatchNorm2d`` for ``SyncBatchNorm`` keeping
+    parameters, buffers and names (Apex ``convert_syncbn_model`` contract)."""
+    if isinstance(module, BatchNorm2d) and not isinstance(module, SyncBatchNorm):
+        new = SyncBatchNorm(module.num_features, module.eps, module.momentum, process_group)
+        new.weight, new.bias = module.weight, module.bias
+        new._buffers.update(module._buffers)
+        new.training = module.training
+        return new
+    for name, child in list(module.named_children()):
+        module._modules[name] = convert_syncbn_model(child, process_group)
+    return module
