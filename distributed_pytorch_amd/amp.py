@@ -83,8 +83,8 @@ def entry_for(param: torch.Tensor) -> _Entry:
 def compute_copy(param: torch.Tensor, like: torch.Tensor) -> Optional[torch.Tensor]:
     """Low-precision compute copy of ``param`` for an op whose input is ``like``;
     ``None`` when the op should use ``param`` itself."""
-    if param.dtype == like.dtype or not like.dtype.is_floating_point:
-        return None
+    if param.dtype == like.dtype or not like.dtype.is_floating_point or param.is_cuda:
+        return None       # GPU: ops/hip_ops.py owns the (cast / padded / transposed) compute copies
     e = entry_for(param)
     if e.lp is None or e.lp.dtype != like.dtype or e.lp.device != param.device \
             or e.version != param._version:

@@ -74,10 +74,15 @@ PYBIND11_MODULE(_C, m) {
   m.def("bn_stats", [](uintptr_t x, long M, int C, int dtype, uintptr_t partial, int nblk, uintptr_t s) {
     bn_stats_launch(ptr<const void>(x), M, C, dtype, ptr<float>(partial), nblk, st(s));
   });
-  m.def("bn_finalize", [](uintptr_t partial, int nparts, int C, double count, uintptr_t gamma, uintptr_t beta,
+  m.def("bn_fold_partials", [](uintptr_t partial, int nparts, int C, uintptr_t out, int nout, uintptr_t s) {
+    bn_fold_partials_launch(ptr<const float>(partial), nparts, C, ptr<float>(out), nout, st(s));
+  });
+  m.def("bn_finalize", [](uintptr_t partial, int nparts, int C, double count, uintptr_t count_dev, uintptr_t gamma,
+                          uintptr_t beta,
                           float eps, float momentum, uintptr_t rm, uintptr_t rv, uintptr_t nbt, uintptr_t mean,
                           uintptr_t invstd, uintptr_t scale, uintptr_t shift, uintptr_t s) {
-    bn_finalize_launch(ptr<const float>(partial), nparts, C, count, ptr<const float>(gamma), ptr<const float>(beta),
+    bn_finalize_launch(ptr<const float>(partial), nparts, C, count, ptr<const float>(count_dev),
+                       ptr<const float>(gamma), ptr<const float>(beta),
                        eps, momentum, ptr<float>(rm), ptr<float>(rv), ptr<long>(nbt), ptr<float>(mean),
                        ptr<float>(invstd), ptr<float>(scale), ptr<float>(shift), st(s));
   });
@@ -101,10 +106,10 @@ PYBIND11_MODULE(_C, m) {
   });
   m.def("bn_bwd_apply", [](uintptr_t dy, uintptr_t x, uintptr_t y, uintptr_t dx, uintptr_t dres, long M, int C,
                            int dtype, uintptr_t mean, uintptr_t invstd, uintptr_t gamma, uintptr_t dgamma,
-                           uintptr_t dbeta, double count, int relu, uintptr_t s) {
+                           uintptr_t dbeta, double count, uintptr_t count_dev, int relu, uintptr_t s) {
     bn_bwd_apply_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const void>(y), ptr<void>(dx), ptr<void>(dres), M,
                         C, dtype, ptr<const float>(mean), ptr<const float>(invstd), ptr<const float>(gamma),
-                        ptr<const float>(dgamma), ptr<const float>(dbeta), count, relu, st(s));
+                        ptr<const float>(dgamma), ptr<const float>(dbeta), count, ptr<const float>(count_dev), relu, st(s));
   });
 
   // ---- pooling

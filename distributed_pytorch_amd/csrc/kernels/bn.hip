@@ -105,13 +105,14 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   const float* __restrict__ count_dev, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var,
                                    long* num_batches_tracked, float* mean, float* invstd, float* scale,
                                    float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   if (c >= C) return;
+  if (count_dev != nullptr) count = (double)count_dev[0];
   double s1 = 0.0, s2 = 0.0;
   for (int k = 0; k < nparts; ++k) {
     s1 += (double)partial[((size_t)k * 2 + 0) * C + c];
@@ -155,6 +156,29 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, int npart
   o2[c] = (float)s2;
 }
 
+// [nparts][2][C] -> [nout][2][C]: block (cx, j) folds parts [j*chunk, (j+1)*chunk) of 64 channels,
+// 4 part lanes x 64 channel lanes (256-byte coalesced rows), fixed order => deterministic.
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                            float* __restrict__ out, int chunk) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int p0 = blockIdx.y * chunk, p1 = min(nparts, p0 + chunk);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int k = p0 + pl; k < p1; k += 4) {
+      s1 += partial[((size_t)k * 2 + 0) * C + c];
+      s2 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+  red[0][pl][cl] = s1;
+  red[1][pl][cl] = s2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    out[((size_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    out[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, long nchunks, int cc,
@@ -196,8 +220,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float inv_count,
-                                                           int relu) {
+                                                           const float* __restrict__ count_dev, int relu) {
   constexpr int VEC = 16 / (int)sizeof(T);
+  if (count_dev != nullptr) inv_count = 1.f / count_dev[0];
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
     const int c0 = (int)(i % cc) * VEC;
@@ -265,6 +290,14 @@ int bn_partial_rows(long M, int C) {
   return (int)nblk;
 }
 
+void bn_fold_partials_launch(const float* partial, int nparts, int C, float* out, int nout, hipStream_t s) {
+  if (nparts <= 0 || nout <= 0) return;
+  const int chunk = (nparts + nout - 1) / nout;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(ceil_div(C, 64), nout), dim3(256), 0, s, partial, nparts, C, out,
+                     chunk);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
 void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, int nblk, hipStream_t s) {
   col_reduce<0>(x, nullptr, nullptr, M, C, dtype, nullptr, nullptr, 0, partial, nblk, s);
 }
@@ -275,12 +308,13 @@ void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, 
   col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu, partial, nblk, s);
 }
 
-void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* gamma,
+void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* count_dev,
+                        const float* gamma,
                         const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, long* num_batches_tracked, float* mean, float* invstd,
                         float* scale, float* shift, hipStream_t s) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partial, nparts, C, count,
-                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd,
+                     count_dev, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd,
                      scale, shift);
   DPA_CHECK_HIP(hipGetLastError());
 }
@@ -323,7 +357,7 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
 void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
                          int C, int dtype, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, double count,
-                         int relu, hipStream_t s) {
+                         const float* count_dev, int relu, hipStream_t s) {
   check_c(C, dtype);
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
@@ -333,15 +367,15 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
   if (dtype == kF32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
                        (const float*)x, (const float*)y, (float*)dx, (float*)dres, nchunks, C / vec, mean,
-                       invstd, gamma, dgamma, dbeta, ic, relu);
+                       invstd, gamma, dgamma, dbeta, ic, count_dev, relu);
   else if (dtype == kBF16)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)dx, (bf16_t*)dres, nchunks, C / vec, mean,
-                       invstd, gamma, dgamma, dbeta, ic, relu);
+                       invstd, gamma, dgamma, dbeta, ic, count_dev, relu);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)dy,
                        (const f16_t*)x, (const f16_t*)y, (f16_t*)dx, (f16_t*)dres, nchunks, C / vec, mean,
-                       invstd, gamma, dgamma, dbeta, ic, relu);
+                       invstd, gamma, dgamma, dbeta, ic, count_dev, relu);
   DPA_CHECK_HIP(hipGetLastError());
 }
 

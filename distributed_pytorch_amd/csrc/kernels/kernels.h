@@ -47,9 +47,12 @@ int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split);
 // ------------------------------------------------------------------------------ bn.hip
 // x, y, residual, dy, dx: [M][C] (NHWC flattened), stats fp32.
 int bn_partial_rows(long M, int C);
+// folds [nparts][2][C] partials into [nout][2][C] (nout*ceil(nparts/nout) >= nparts; empty parts give 0)
+void bn_fold_partials_launch(const float* partial, int nparts, int C, float* out, int nout, hipStream_t s);
 void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, int nblk, hipStream_t s);
 // partial: [nparts][2][C] (sum, sumsq) over `count` rows total -> mean, invstd, scale/shift, running update
-void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* gamma,
+void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* count_dev,
+                        const float* gamma,
                         const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, long* num_batches_tracked, float* mean, float* invstd,
                         float* scale, float* shift, hipStream_t s);
@@ -68,7 +71,7 @@ void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgam
 void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
                          int C, int dtype, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, double count,
-                         int relu, hipStream_t s);
+                         const float* count_dev, int relu, hipStream_t s);
 
 // ------------------------------------------------------------------------------ pool.hip
 void maxpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,

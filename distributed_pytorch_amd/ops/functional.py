@@ -175,6 +175,8 @@ def topk_correct(output: torch.Tensor, target: torch.Tensor, topk: Sequence[int]
 
 def loss_and_metrics(logits: torch.Tensor, target: torch.Tensor):
     """-> (mean loss with grad, float32[4] record = loss*n, correct@1, correct@5, n)."""
+    if _on_gpu(logits):
+        return _hip().loss_and_metrics(logits, target)
     loss = cross_entropy(logits, target)
     with torch.no_grad():
         n = float(target.numel())

@@ -1,0 +1,966 @@
+"""GPU implementations of the functional ops: autograd wrappers over the hand-written
+gfx950 kernels in ``csrc/`` (no ATen / MIOpen / rocBLAS compute on this path).
+
+Every wrapper allocates its outputs with ``torch.empty`` (caching allocator, so a
+step can be captured in a hipGraph), launches on torch's *current* stream and never
+synchronises with the host.  Tensors are NHWC; conv weights are logical
+``[K, C, R, S]`` whose memory is KRSC.
+
+Reference parity: these ops are what cuDNN / cuBLAS / ATen / Apex executed for the
+reference's ``model(images)``, ``criterion``, ``loss.backward()`` and
+``optimizer.step()`` (``nd_imagenet.py:291-303``, ``imagenet_ddp_apex.py:372-383``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .. import backend
+
+_C = None
+
+
+def C():
+    global _C
+    if _C is None:
+        _C = backend.require()
+    return _C
+
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _dt(t) -> int:
+    try:
+        return _DT[t if isinstance(t, torch.dtype) else t.dtype]
+    except KeyError:
+        raise TypeError("unsupported dtype %r for HIP kernels" % (t,))
+
+
+def _vec(dtype: torch.dtype) -> int:
+    return 4 if dtype == torch.float32 else 8
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------
+# weight compute copies (cast / channel padding / dgrad transposes), cached per parameter
+# ------------------------------------------------------------------------------------------
+_generation = 0          # bumped by optimizers that rewrite parameters through raw pointers
+
+
+def bump_generation() -> None:
+    global _generation
+    _generation += 1
+
+
+class _WCache:
+    __slots__ = ("wc", "wc_key", "wc_stamp", "wt", "wt_key", "wt_stamp")
+
+    def __init__(self):
+        self.wc = self.wt = None
+        self.wc_key = self.wt_key = None
+        self.wc_stamp = self.wt_stamp = None
+
+
+def _cache(p: torch.Tensor) -> _WCache:
+    c = getattr(p, "_dpa_wcache", None)
+    if c is None:
+        c = _WCache()
+        p._dpa_wcache = c
+    return c
+
+
+def _stamp(p: torch.Tensor):
+    return (p._version, _generation, p.data_ptr())
+
+
+def _krsc_view(w: torch.Tensor) -> torch.Tensor:
+    """[K,C,R,S] logical -> [K,R,S,C] tensor that is contiguous in memory (no copy when the
+    parameter already is channels_last)."""
+    v = w.detach().permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv_weight(w: torch.Tensor, dtype: torch.dtype, cpad: int) -> torch.Tensor:
+    """Compute copy [K, R, S, cpad] in ``dtype`` (the parameter itself when nothing changes)."""
+    K, Cw, R, S = w.shape
+    c = _cache(w)
+    key = (dtype, cpad)
+    if c.wc is not None and c.wc_key == key and c.wc_stamp == _stamp(w):
+        return c.wc
+    src = _krsc_view(w)
+    if cpad == Cw and dtype == w.dtype:
+        wc = src
+    else:
+        if c.wc is None or c.wc_key != key:
+            c.wc = torch.zeros((K, R, S, cpad), dtype=dtype, device=w.device)
+        wc = c.wc
+        if cpad == Cw:
+            C().cast(src.data_ptr(), _dt(src), wc.data_ptr(), _dt(dtype), src.numel(), _stream())
+        else:
+            # channel padding (stem only): [K*R*S] "images" of one pixel with C channels -> cpad
+            C().nchw_to_nhwc(src.data_ptr(), wc.data_ptr(), K * R * S, Cw, 1, cpad, _dt(src), _dt(dtype),
+                             _stream())
+    c.wc, c.wc_key, c.wc_stamp = wc, key, _stamp(w)
+    return wc
+
+
+def conv_weight_t(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """dgrad operand [C, R, S, K] in ``dtype``."""
+    K, Cw, R, S = w.shape
+    c = _cache(w)
+    if c.wt is not None and c.wt_key == dtype and c.wt_stamp == _stamp(w):
+        return c.wt
+    src = _krsc_view(w)
+    if c.wt is None or c.wt_key != dtype:
+        c.wt = torch.empty((Cw, R, S, K), dtype=dtype, device=w.device)
+    C().transpose_ktc(src.data_ptr(), c.wt.data_ptr(), K, R * S, Cw, _dt(src), _dt(dtype), _stream())
+    c.wt_key, c.wt_stamp = dtype, _stamp(w)
+    return c.wt
+
+
+def linear_weight(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    c = _cache(w)
+    key = (dtype, 0)
+    if c.wc is not None and c.wc_key == key and c.wc_stamp == _stamp(w):
+        return c.wc
+    src = w.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    if dtype == w.dtype:
+        wc = src
+    else:
+        if c.wc is None or c.wc_key != key:
+            c.wc = torch.empty(w.shape, dtype=dtype, device=w.device)
+        wc = c.wc
+        C().cast(src.data_ptr(), _dt(src), wc.data_ptr(), _dt(dtype), src.numel(), _stream())
+    c.wc, c.wc_key, c.wc_stamp = wc, key, _stamp(w)
+    return wc
+
+
+def linear_weight_t(w: torch.Tensor, dtype: torch.dtype, outp: int) -> torch.Tensor:
+    """[in, outp] (zero padded columns) for the input-gradient GEMM."""
+    out_f, in_f = w.shape
+    c = _cache(w)
+    key = (dtype, outp)
+    if c.wt is not None and c.wt_key == key and c.wt_stamp == _stamp(w):
+        return c.wt
+    src = w.detach()
+    if not src.is_contiguous():
+        src = src.contiguous()
+    if c.wt is None or c.wt_key != key:
+        c.wt = torch.zeros((in_f, outp), dtype=dtype, device=w.device)
+    if outp == out_f:
+        C().transpose_ktc(src.data_ptr(), c.wt.data_ptr(), out_f, 1, in_f, _dt(src), _dt(dtype), _stream())
+    else:
+        tmp = torch.empty((in_f, out_f), dtype=dtype, device=w.device)
+        C().transpose_ktc(src.data_ptr(), tmp.data_ptr(), out_f, 1, in_f, _dt(src), _dt(dtype), _stream())
+        # widen rows: "images" of in_f pixels... reuse the channel-padding kernel (C=out_f -> outp)
+        C().nchw_to_nhwc(tmp.data_ptr(), c.wt.data_ptr(), in_f, out_f, 1, outp, _dt(dtype), _dt(dtype), _stream())
+    c.wt_key, c.wt_stamp = key, _stamp(w)
+    return c.wt
+
+
+# ------------------------------------------------------------------------------------------
+# tap tables
+# ------------------------------------------------------------------------------------------
+_taps: Dict[tuple, torch.Tensor] = {}
+
+
+def _tap_table(device, entries) -> torch.Tensor:
+    key = (device.index, tuple(entries))
+    t = _taps.get(key)
+    if t is None:
+        t = torch.tensor([v for e in entries for v in e], dtype=torch.int32, device=device)
+        _taps[key] = t
+    return t
+
+
+def _fprop_taps(R, S, ph, pw):
+    return tuple((r - ph, s - pw, r * S + s) for r in range(R) for s in range(S))
+
+
+def _dgrad_classes(R, S, sh, sw, ph, pw):
+    """Per output-parity class (py, px): taps (dy, dx, wtap) over the dY grid."""
+    out = []
+    for py in range(sh):
+        for px in range(sw):
+            taps = []
+            for r in range(R):
+                if (py + ph - r) % sh:
+                    continue
+                for s in range(S):
+                    if (px + pw - s) % sw:
+                        continue
+                    taps.append(((py + ph - r) // sh, (px + pw - s) // sw, r * S + s))
+            out.append((py, px, tuple(taps)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------
+def _conv_out(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
+           scatter=None, relu=False, dtype=None, out_dtype=None):
+    flags = (C().IGEMM_RELU if relu else 0)
+    OHF = OWF = OSY = OSX = OY0 = OX0 = 0
+    if scatter is not None:
+        flags |= C().IGEMM_SCATTER
+        OHF, OWF, OSY, OSX, OY0, OX0 = scatter
+    C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
+              ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
+              _dt(dtype), _dt(out_dtype), _stream())
+
+
+def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of [M, C] (bias gradients) through the BN column reducer."""
+    M, Cc = dy2d.shape
+    nblk = C().bn_partial_rows(M, Cc)
+    part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dy2d.device)
+    C().bn_stats(dy2d.data_ptr(), M, Cc, _dt(dy2d), part.data_ptr(), nblk, _stream())
+    s1 = torch.empty(Cc, dtype=torch.float32, device=dy2d.device)
+    s2 = torch.empty(Cc, dtype=torch.float32, device=dy2d.device)
+    C().bn_bwd_finalize(part.data_ptr(), nblk, Cc, s2.data_ptr(), s1.data_ptr(), _stream())
+    return s1
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, IH, IW, Cx = x.shape
+        K, Cw, R, S = weight.shape
+        if Cx < Cw or Cx % _vec(x.dtype):
+            raise ValueError("conv2d: input channels %d incompatible with weight %s" % (Cx, tuple(weight.shape)))
+        sh, sw = stride
+        ph, pw = padding
+        OH, OW = _conv_out(IH, R, sh, ph), _conv_out(IW, S, sw, pw)
+        wc = conv_weight(weight, x.dtype, Cx)
+        y = torch.empty((NB, OH, OW, K), dtype=x.dtype, device=x.device)
+        M = NB * OH * OW
+        stats = None
+        if want_stats:
+            tiles = (M + C().igemm_tile_m(_dt(x)) - 1) // C().igemm_tile_m(_dt(x))
+            stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+        taps = _tap_table(x.device, _fprop_taps(R, S, ph, pw))
+        bias_f = None
+        if bias is not None:
+            bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
+        _igemm(x, wc, y, bias_f, stats, taps, M, K, Cx, R * S, Cx, R * S * Cx, K, IH, IW, sh, sw, OH, OW,
+               relu=relu, dtype=x.dtype, out_dtype=x.dtype)
+        ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        x, weight, y = ctx.saved_tensors
+        (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
+        NB, IH, IW, Cx = x.shape
+        K, Cw, R, S = weight.shape
+        OH, OW = dy.shape[1], dy.shape[2]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        M = NB * OH * OW
+        st = _stream()
+        if relu:
+            dym = torch.empty_like(dy)
+            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
+            dy = dym
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and needs_input_grad:
+            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw))
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy.view(M, K)).to(ctx.saved_tensors[1].dtype)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv_dgrad(dy, weight, xshape, stride, padding):
+    NB, IH, IW, Cx = xshape
+    K, Cw, R, S = weight.shape
+    sh, sw = stride
+    ph, pw = padding
+    OH, OW = dy.shape[1], dy.shape[2]
+    wt = conv_weight_t(weight, dy.dtype)          # [Cw, R, S, K]
+    if Cx != Cw:
+        raise ValueError("dgrad into a channel-padded input is not supported (stem has no input grad)")
+    classes = _dgrad_classes(R, S, sh, sw, ph, pw)
+    need_zero = any(len(t) == 0 for _, _, t in classes)
+    dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
+    for py, px, taps in classes:
+        if not taps:
+            continue
+        SH, SW = (IH - py + sh - 1) // sh, (IW - px + sw - 1) // sw   # sub-grid extent
+        if SH <= 0 or SW <= 0:
+            continue
+        tt = _tap_table(dy.device, taps)
+        scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
+        _igemm(dy, wt, dx, None, None, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
+               SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype)
+    return dx
+
+
+def conv_wgrad(dy, x, weight, stride, padding):
+    NB, IH, IW, Cx = x.shape
+    K, Cw, R, S = weight.shape
+    sh, sw = stride
+    ph, pw = padding
+    OH, OW = dy.shape[1], dy.shape[2]
+    M = NB * OH * OW
+    Ktot = R * S * Cx
+    splits, pps = C().wgrad_choose_splits(M, K, Ktot, _dt(dy))
+    slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
+    taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
+    st = _stream()
+    C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
+              sh, sw, OH, OW, splits, pps, _dt(dy), st)
+    gdtype = weight.dtype
+    if Cx == Cw:
+        g = torch.empty((K, R, S, Cw), dtype=gdtype, device=dy.device)
+        C().slab_reduce(slab.data_ptr(), splits, K * Ktot, g.data_ptr(), _dt(gdtype), 0.0, st)
+    else:
+        full = torch.empty((K, R, S, Cx), dtype=torch.float32, device=dy.device)
+        C().slab_reduce(slab.data_ptr(), splits, K * Ktot, full.data_ptr(), 0, 0.0, st)
+        g = torch.empty((K, R, S, Cw), dtype=gdtype, device=dy.device)
+        # drop the padded channels: "NCHW -> NHWC" over K*R*S one-pixel images keeps the first Cw of Cx
+        _slice_channels(full, g, Cw)
+    return g.permute(0, 3, 1, 2)       # logical [K, C, R, S] with channels_last strides
+
+
+def _slice_channels(src: torch.Tensor, dst: torch.Tensor, keep: int) -> None:
+    """dst[..., :keep] = src[..., :keep] for tiny tensors (stem weight gradient)."""
+    n = src.numel() // src.shape[-1]
+    # [n][Cx] -> transpose to [Cx][n] -> take first `keep` rows -> transpose back
+    Cx = src.shape[-1]
+    tmp = torch.empty((Cx, n), dtype=torch.float32, device=src.device)
+    C().transpose_ktc(src.data_ptr(), tmp.data_ptr(), n, 1, Cx, 0, 0, _stream())
+    C().transpose_ktc(tmp.data_ptr(), dst.data_ptr(), keep, 1, n, 0, _dt(dst), _stream())
+
+
+def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad):
+    return _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
+                         bool(needs_input_grad))
+
+
+# ------------------------------------------------------------------------------------------
+# batch norm (+ residual, + ReLU), SyncBN
+# ------------------------------------------------------------------------------------------
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _fold(part: torch.Tensor, C_: int, limit: int = 64) -> torch.Tensor:
+    n = part.shape[0]
+    if n <= limit:
+        return part
+    nout = 32
+    out = torch.empty((nout, 2, C_), dtype=torch.float32, device=part.device)
+    C().bn_fold_partials(part.data_ptr(), n, C_, out.data_ptr(), nout, _stream())
+    return out
+
+
+def _group_size(group) -> int:
+    import torch.distributed as dist
+
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(None if group == "world" else group)
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    import torch.distributed as dist
+
+    dist.all_reduce(t, group=None if group == "world" else group)
+
+
+class _BNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, momentum, eps, relu, stats,
+                group):
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        st = _stream()
+        dev = x.device
+        if stats is None:
+            nblk = C().bn_partial_rows(M, Cc)
+            stats = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
+            C().bn_stats(x.data_ptr(), M, Cc, _dt(x), stats.data_ptr(), nblk, st)
+        part = _fold(stats, Cc)
+        count = float(M)
+        count_dev = None
+        world = _group_size(group)
+        if world > 1:
+            # SyncBN: all-reduce [sum(C), sumsq(C), rows] -- one small message per layer
+            packed = torch.empty(2 * Cc + 1, dtype=torch.float32, device=dev)
+            C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, packed[Cc:2 * Cc].data_ptr(),
+                                packed[:Cc].data_ptr(), st)
+            packed[2 * Cc:].fill_(float(M))
+            _all_reduce_sum(packed, group)
+            count_dev = packed[2 * Cc:]
+            part = packed[:2 * Cc].view(1, 2, Cc)
+        g32, b32 = _f32(weight.detach()), _f32(bias.detach())
+        coef = torch.empty((4, Cc), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+        C().bn_finalize(part.data_ptr(), part.shape[0], Cc, count, _p(count_dev), g32.data_ptr(), b32.data_ptr(),
+                        eps, momentum, _p(running_mean), _p(running_var), _p(nbt), coef[0].data_ptr(),
+                        coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+        if residual is not None and not residual.is_contiguous():
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
+                     coef[3].data_ptr(), 1 if relu else 0, st)
+        ctx.save_for_backward(x, y if relu else None, weight, coef, count_dev)
+        ctx.cfg = (relu, residual is not None, group, count)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, coef, count_dev = ctx.saved_tensors
+        relu, has_res, group, count = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        st = _stream()
+        dev = x.device
+        nblk = C().bn_partial_rows(M, Cc)
+        part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
+        C().bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), _p(y), M, Cc, _dt(x), coef[0].data_ptr(),
+                          coef[1].data_ptr(), 1 if relu else 0, part.data_ptr(), nblk, st)
+        part = _fold(part, Cc)
+        sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)     # [dgamma, dbeta] local
+        C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, sums[0].data_ptr(), sums[1].data_ptr(), st)
+        gsums = sums
+        if _group_size(group) > 1:
+            gsums = sums.clone()
+            _all_reduce_sum(gsums, group)
+        g32 = _f32(weight.detach())
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        C().bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), _p(dres), M, Cc, _dt(x),
+                         coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), gsums[0].data_ptr(),
+                         gsums[1].data_ptr(), count, _p(count_dev), 1 if relu else 0, st)
+        dgamma = sums[0].to(weight.dtype) if ctx.needs_input_grad[1] else None
+        dbeta = sums[1].to(weight.dtype) if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+class _BNEvalFn(torch.autograd.Function):
+    """Inference-mode BN (running statistics): y = x*scale + shift (+res)(relu)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, eps, relu):
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        st = _stream()
+        coef = torch.empty((3, Cc), dtype=torch.float32, device=x.device)  # scale, shift, zero
+        coef[2].zero_()
+        C().bn_eval_coeffs(_f32(weight.detach()).data_ptr(), _f32(bias.detach()).data_ptr(),
+                           _f32(running_mean).data_ptr(), _f32(running_var).data_ptr(), eps, Cc,
+                           coef[0].data_ptr(), coef[1].data_ptr(), st)
+        if residual is not None and not residual.is_contiguous():
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[0].data_ptr(),
+                     coef[1].data_ptr(), 1 if relu else 0, st)
+        ctx.save_for_backward(y if relu else None, coef)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, coef = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        Cc = dy.shape[-1]
+        M = dy.numel() // Cc
+        st = _stream()
+        if relu:
+            dym = torch.empty_like(dy)
+            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
+            dy = dym
+        dx = torch.empty_like(dy)
+        C().bn_apply(dy.data_ptr(), 0, dx.data_ptr(), M, Cc, _dt(dy), coef[0].data_ptr(), coef[2].data_ptr(), 0, st)
+        return dx, None, None, (dy if has_res else None), None, None, None, None
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps,
+               relu, residual, stats, group):
+    if training or running_mean is None:
+        return _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
+                           running_var if training else None, num_batches_tracked if training else None,
+                           float(momentum if momentum is not None else 0.1), float(eps), bool(relu), stats, group)
+    return _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), bool(relu))
+
+
+# ------------------------------------------------------------------------------------------
+# pooling / elementwise
+# ------------------------------------------------------------------------------------------
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, IH, IW, Cc = x.shape
+        OH, OW = _conv_out(IH, k[0], s[0], p[0]), _conv_out(IW, k[1], s[1], p[1])
+        y = torch.empty((NB, OH, OW, Cc), dtype=x.dtype, device=x.device)
+        C().maxpool_fwd(x.data_ptr(), y.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1],
+                        _dt(x), _stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (k, s, p, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        k, s, p, OH, OW = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        NB, IH, IW, Cc = x.shape
+        dx = torch.empty_like(x)
+        C().maxpool_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
+                        p[0], p[1], _dt(x), _stream())
+        return dx, None, None, None
+
+
+def max_pool2d(x, k, s, p):
+    return _MaxPoolFn.apply(x, tuple(k), tuple(s), tuple(p))
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, o):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, IH, IW, Cc = x.shape
+        y = torch.empty((NB, o[0], o[1], Cc), dtype=x.dtype, device=x.device)
+        C().avgpool_fwd(x.data_ptr(), y.data_ptr(), NB, IH, IW, Cc, o[0], o[1], _dt(x), _stream())
+        ctx.cfg = (x.shape, o)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (NB, IH, IW, Cc), o = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty((NB, IH, IW, Cc), dtype=dy.dtype, device=dy.device)
+        C().avgpool_bwd(dy.data_ptr(), dx.data_ptr(), NB, IH, IW, Cc, o[0], o[1], _dt(dy), _stream())
+        return dx, None
+
+
+def adaptive_avg_pool2d(x, o):
+    if x.shape[1] == o[0] and x.shape[2] == o[1]:
+        return x                      # identity at 224x224 for AlexNet (6x6) / VGG (7x7)
+    return _AvgPoolFn.apply(x, tuple(o))
+
+
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(x)
+        C().relu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _dt(x), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dy)
+        C().relu_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), dy.numel(), _dt(dy), _stream())
+        return dx
+
+
+def relu(x):
+    return _ReluFn.apply(x)
+
+
+class _AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        y = torch.empty_like(a)
+        C().add_relu_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _dt(a), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dy)
+        C().relu_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), dy.numel(), _dt(dy), _stream())
+        return dx, dx
+
+
+def add_relu(a, b):
+    return _AddReluFn.apply(a, b)
+
+
+_dropout_offset = 0
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        global _dropout_offset
+        x = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        C().dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), p, seed, _dropout_offset, _dt(x),
+                        _stream())
+        _dropout_offset += x.numel()
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dy)
+        C().dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, _dt(dy), _stream())
+        return dx, None
+
+
+def dropout(x, p):
+    return _DropoutFn.apply(x, float(p))
+
+
+# ------------------------------------------------------------------------------------------
+# linear
+# ------------------------------------------------------------------------------------------
+_ONE_TAP = ((0, 0, 0),)
+
+
+def _padded_rows(t: torch.Tensor, n: int, dtype: torch.dtype) -> torch.Tensor:
+    """[M, n] tensor -> contiguous [M, round_up(n, 8)] buffer in ``dtype`` with zero pad columns."""
+    M = t.shape[0]
+    ld = _round_up(n, 8)
+    st = _stream()
+    if ld == n:
+        src = t if t.is_contiguous() else t.contiguous()
+        if src.dtype == dtype:
+            return src
+        out = torch.empty((M, n), dtype=dtype, device=t.device)
+        C().cast(src.data_ptr(), _dt(src), out.data_ptr(), _dt(dtype), src.numel(), st)
+        return out
+    src = t.contiguous()
+    out = torch.empty((M, ld), dtype=dtype, device=t.device)
+    C().nchw_to_nhwc(src.data_ptr(), out.data_ptr(), M, n, 1, ld, _dt(src), _dt(dtype), st)
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, out_dtype):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        M, in_f = x2.shape
+        out_f = weight.shape[0]
+        if in_f % _vec(x2.dtype):
+            raise ValueError("linear: in_features must be a multiple of %d" % _vec(x2.dtype))
+        wc = linear_weight(weight, x2.dtype)
+        odt = out_dtype or x2.dtype
+        ldc = _round_up(out_f, 8)
+        buf = torch.empty((M, ldc), dtype=odt, device=x.device)
+        taps = _tap_table(x.device, _ONE_TAP)
+        bias_f = None if bias is None else _f32(bias.detach())
+        _igemm(x2, wc, buf, bias_f, None, taps, M, out_f, in_f, 1, in_f, in_f, ldc, 1, 1, 1, 1, 1, 1,
+               relu=relu, dtype=x2.dtype, out_dtype=odt)
+        y = buf[:, :out_f] if ldc != out_f else buf
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.cfg = (relu, bias is not None, lead)
+        return y.reshape(*lead, out_f) if len(lead) != 1 else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        relu, has_bias, lead = ctx.cfg
+        M, in_f = x2.shape
+        out_f = weight.shape[0]
+        st = _stream()
+        cdt = x2.dtype
+        dy2 = dy.reshape(M, out_f)
+        if relu:
+            dyc, yc = dy2.contiguous(), y.contiguous()
+            dym = torch.empty_like(dyc)
+            C().relu_bwd(yc.data_ptr(), dyc.data_ptr(), dym.data_ptr(), dyc.numel(), _dt(dyc), st)
+            dy2 = dym
+        dyp = _padded_rows(dy2, out_f, cdt)          # [M, outp], zero pad columns
+        outp = dyp.shape[1]
+        dx = dw = db = None
+        taps = _tap_table(dy.device, _ONE_TAP)
+        if ctx.needs_input_grad[0]:
+            wt = linear_weight_t(weight, cdt, outp)   # [in, outp]
+            dx = torch.empty((M, in_f), dtype=cdt, device=dy.device)
+            _igemm(dyp, wt, dx, None, None, taps, M, in_f, outp, 1, outp, outp, in_f, 1, 1, 1, 1, 1, 1,
+                   dtype=cdt, out_dtype=cdt)
+            dx = dx.reshape(*lead, in_f)
+        if ctx.needs_input_grad[1]:
+            splits, pps = C().wgrad_choose_splits(M, outp, in_f, _dt(cdt))
+            slab = torch.empty((splits, outp, in_f), dtype=torch.float32, device=dy.device)
+            C().wgrad(dyp.data_ptr(), x2.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, outp, in_f, 1,
+                      outp, in_f, 1, 1, 1, 1, 1, 1, splits, pps, _dt(cdt), st)
+            full = torch.empty((outp, in_f), dtype=weight.dtype, device=dy.device)
+            C().slab_reduce(slab.data_ptr(), splits, outp * in_f, full.data_ptr(), _dt(weight.dtype), 0.0, st)
+            dw = full[:out_f]
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dyp)[:out_f].to(weight.dtype)
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias, relu, w_lp, out_dtype):
+    return _LinearFn.apply(x, weight, bias, bool(relu), out_dtype)
+
+
+# ------------------------------------------------------------------------------------------
+# loss / metrics
+# ------------------------------------------------------------------------------------------
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, metrics):
+        N, Cc = logits.shape
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        ldl = logits.stride(0)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        rowbuf = torch.empty((3, N), dtype=torch.float32, device=logits.device)
+        need_grad = logits.requires_grad
+        dl = torch.empty((N, ldl), dtype=logits.dtype, device=logits.device) if need_grad else None
+        tgt = target if target.dtype == torch.int64 and target.is_contiguous() else target.long().contiguous()
+        C().xent_fwd_bwd(logits.data_ptr(), tgt.data_ptr(), N, Cc, ldl, _dt(logits), loss.data_ptr(), _p(dl),
+                         rowbuf.data_ptr(), _p(metrics), _stream())
+        ctx.dl = dl
+        ctx.ncls = Cc
+        if metrics is not None:
+            ctx.mark_dirty(metrics)
+            return loss, metrics
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout, *unused):
+        dl = ctx.dl
+        if dl is None:
+            return None, None, None
+        ctx.dl = None
+        g = gout if gout.dtype == torch.float32 else gout.float()
+        g = g.contiguous()
+        C().xent_bwd_scale(dl.data_ptr(), dl.numel(), _dt(dl), g.data_ptr(), _stream())
+        out = dl[:, :ctx.ncls] if dl.shape[1] != ctx.ncls else dl
+        return out, None, None
+
+
+def cross_entropy(logits, target):
+    return _XentFn.apply(logits, target, None)
+
+
+def loss_and_metrics(logits, target):
+    """-> (mean loss, float32[4] = loss*n, correct@1, correct@5, n), one fused launch pair."""
+    rec = torch.zeros(4, dtype=torch.float32, device=logits.device)
+    loss, rec = _XentFn.apply(logits, target, rec)
+    return loss, rec.detach()
+
+
+def topk_correct(output, target, topk):
+    rec = torch.zeros(4, dtype=torch.float32, device=output.device)
+    with torch.no_grad():
+        _XentFn.apply(output.detach(), target, rec)
+    picks = []
+    for k in topk:
+        if k == 1:
+            picks.append(rec[1])
+        elif k == 5 or k == min(5, output.shape[1]):
+            picks.append(rec[2])
+        else:
+            z = output.float()
+            zt = z.gather(1, target.view(-1, 1))
+            picks.append(((z > zt).sum(1) < k).sum().float())
+    return torch.stack(picks)
+
+
+# ------------------------------------------------------------------------------------------
+# input pipeline
+# ------------------------------------------------------------------------------------------
+_norm_consts: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def normalize_u8(x, dtype, pad_c, mean, std, input_layout):
+    key = (x.device.index, tuple(mean), tuple(std))
+    if key not in _norm_consts:
+        m = torch.tensor([v * 255.0 for v in mean], dtype=torch.float32, device=x.device)
+        s = torch.tensor([1.0 / (v * 255.0) for v in std], dtype=torch.float32, device=x.device)
+        _norm_consts[key] = (m, s)
+    m, s = _norm_consts[key]
+    x = x if x.is_contiguous() else x.contiguous()
+    nchw = input_layout == "nchw"
+    if nchw:
+        NB, cin, H, W = x.shape
+    else:
+        NB, H, W, cin = x.shape
+    cout = max(pad_c or 0, _round_up(cin, _vec(dtype)))
+    cout = _round_up(cout, _vec(dtype))
+    y = torch.empty((NB, H, W, cout), dtype=dtype, device=x.device)
+    C().normalize_u8(x.data_ptr(), y.data_ptr(), NB * H * W, cin, cout, H * W, 1 if nchw else 0, m.data_ptr(),
+                     s.data_ptr(), _dt(dtype), _stream())
+    return y
+
+
+def nchw_to_nhwc(x, dtype, pad_c):
+    x = x if x.is_contiguous() else x.contiguous()
+    NB, Cc, H, W = x.shape
+    cout = _round_up(max(pad_c or 0, Cc), _vec(dtype))
+    y = torch.empty((NB, H, W, cout), dtype=dtype, device=x.device)
+    C().nchw_to_nhwc(x.data_ptr(), y.data_ptr(), NB, Cc, H * W, cout, _dt(x), _dt(dtype), _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# optimizer / AMP helpers
+# ------------------------------------------------------------------------------------------
+def multi_tensor_check_finite(grads, found_inf: torch.Tensor) -> None:
+    st = _stream()
+    for g in grads:
+        gg = g if g.is_contiguous() or _dense(g) else g.contiguous()
+        C().check_finite(gg.data_ptr(), gg.numel(), _dt(gg), found_inf.data_ptr(), st)
+
+
+def scaler_update(scale, inv_scale, good_steps, found_inf, growth_interval, growth_factor, backoff_factor,
+                  max_scale, min_scale) -> None:
+    C().scaler_update(scale.data_ptr(), inv_scale.data_ptr(), good_steps.data_ptr(), found_inf.data_ptr(),
+                      int(growth_interval), float(growth_factor), float(backoff_factor), float(max_scale),
+                      float(min_scale), _stream())
+
+
+def _dense(t: torch.Tensor) -> bool:
+    """True when the tensor covers its memory densely (any permutation of a contiguous block)."""
+    if t.is_contiguous():
+        return True
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return True
+    return False
+
+
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    if a.shape != b.shape:
+        return False
+    sa = [s for s, n in zip(a.stride(), a.shape) if n > 1]
+    sb = [s for s, n in zip(b.stride(), b.shape) if n > 1]
+    return sa == sb
+
+
+def _lp_copy_of(p: torch.Tensor):
+    cache = getattr(p, "_dpa_wcache", None)
+    if cache is not None and cache.wc is not None and cache.wc.dtype != torch.float32 \
+            and cache.wc.numel() == p.numel():
+        return cache.wc
+    return None
+
+
+class SgdPlan:
+    """Device-resident tensor tables (one per param group) for the fused multi-tensor SGD launch."""
+
+    def __init__(self, opt):
+        import struct
+
+        chunk = C().sgd_chunk_elems()
+        self.groups = []
+        self.params_with_copies = []
+        for group in opt.param_groups:
+            entries, keep, plist, nchunks = [], [], [], 0
+            g_dtype = lp_dtype = None
+            device = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32:
+                    raise TypeError("FusedSGD HIP path needs fp32 parameters, got %s" % p.dtype)
+                if not _dense(p):
+                    raise ValueError("FusedSGD: parameter is not densely laid out")
+                g = p.grad
+                if not _same_layout(p, g):
+                    g = torch.empty_like(p).copy_(g)
+                    p.grad = g
+                device = p.device
+                buf = opt._momentum_buffer(p) if group["momentum"] != 0 else None
+                if buf is not None and not _same_layout(p, buf):
+                    buf = torch.empty_like(p).copy_(buf)
+                    opt.state[p]["momentum_buffer"] = buf
+                if g_dtype is None:
+                    g_dtype = _dt(g)
+                elif g_dtype != _dt(g):
+                    raise TypeError("FusedSGD: mixed gradient dtypes in one group")
+                lp = _lp_copy_of(p)
+                if lp is not None:
+                    if lp_dtype is None:
+                        lp_dtype = _dt(lp)
+                    elif lp_dtype != _dt(lp):
+                        lp = None
+                n = p.numel()
+                entries.append((p.data_ptr(), g.data_ptr(), _p(buf), _p(lp), n, nchunks))
+                keep.extend([p, g, buf, lp])
+                plist.append((p, lp))
+                nchunks += (n + chunk - 1) // chunk
+            if not entries:
+                continue
+            raw = b"".join(struct.pack("<QQQQqq", *e) for e in entries)
+            assert len(raw) == len(entries) * C().sgd_table_entry_bytes()
+            table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            self.groups.append(dict(group=group, table=table, n=len(entries), chunks=nchunks, g_dtype=g_dtype,
+                                    lp_dtype=lp_dtype if lp_dtype is not None else 0,
+                                    hyper=torch.zeros(6, dtype=torch.float32, device=device), hyper_host=None,
+                                    plist=plist, keep=keep))
+            self.params_with_copies.extend(p for p, lp in plist if lp is not None)
+        self.sig = self.signature(opt)
+
+    @staticmethod
+    def signature(opt):
+        return tuple((p.data_ptr(), p.grad.data_ptr(), _p(_lp_copy_of(p)))
+                     for g in opt.param_groups for p in g["params"] if p.grad is not None)
+
+    def matches(self, opt) -> bool:
+        return self.sig == self.signature(opt)
+
+    def launch(self, opt, scaler) -> None:
+        st = _stream()
+        for gt in self.groups:
+            group = gt["group"]
+            first = 1.0 if opt._steps == 0 else 0.0
+            host = (float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]),
+                    float(group["dampening"]), 1.0 if group["nesterov"] else 0.0, first)
+            if gt["hyper_host"] != host:
+                gt["hyper"].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
+                gt["hyper_host"] = host
+            inv = found = 0
+            if scaler is not None and not scaler.is_identity:
+                inv, found = scaler.inv_scale.data_ptr(), scaler.found_inf.data_ptr()
+            C().sgd_multi_tensor(gt["table"].data_ptr(), gt["n"], gt["chunks"], gt["g_dtype"], gt["lp_dtype"],
+                                 gt["hyper"].data_ptr(), inv, found, st)
+        # parameters changed behind torch's back: derived copies (transposes, padded casts) are stale,
+        # the low-precision copies the kernel wrote are current
+        bump_generation()
+        for gt in self.groups:
+            for p, lp in gt["plist"]:
+                if lp is not None:
+                    p._dpa_wcache.wc_stamp = _stamp(p)

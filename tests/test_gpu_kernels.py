@@ -1,0 +1,293 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op.
+
+Low-precision runs feed the reference the SAME bf16/fp16-rounded inputs (upcast to fp32), so the
+only differences are accumulation order and the final rounding of the output.
+"""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from distributed_pytorch_amd.ops import functional as F  # noqa: E402
+
+DEV = "cuda"
+TOL = {torch.float32: (2e-4, 2e-4), torch.bfloat16: (2e-2, 2e-2), torch.float16: (4e-3, 4e-3)}
+
+
+def _close(a, b, dtype, scale=1.0, what=""):
+    rtol, atol = TOL[dtype]
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol * scale * max(ref, 1.0) + rtol * ref * 0, "%s: max err %g vs ref max %g" % (what, err, ref)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (4, 14, 14, 64, 64, 1, 1, 0),
+    (4, 14, 14, 64, 128, 3, 1, 1),
+    (4, 14, 14, 128, 128, 3, 2, 1),
+    (4, 14, 14, 64, 256, 1, 2, 0),
+    (3, 15, 13, 32, 64, 3, 2, 1),       # odd extents, Cin % 64 != 0
+    (2, 9, 9, 96, 72, 3, 1, 1),         # non-aligned K tiles, Cout tail
+    (2, 32, 32, 3, 64, 7, 2, 3),        # stem (channel padded)
+    (2, 13, 13, 64, 192, 5, 1, 2),      # AlexNet conv2
+    (2, 67, 67, 3, 64, 11, 4, 2),       # AlexNet conv1
+    (2, 7, 7, 512, 512, 3, 1, 1),
+    (5, 7, 7, 256, 1024, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("bias_relu", [False, True])
+def test_conv_fwd_bwd(case, dtype, bias_relu):
+    N, H, W, Cin, Cout, k, s, p = case
+    if bias_relu and k not in (3, 5, 11):
+        pytest.skip("bias/relu epilogue covered on a subset")
+    torch.manual_seed(0)
+    vec = 4 if dtype == torch.float32 else 8
+    Cx = Cin if Cin % vec == 0 else 8
+    x = torch.randn(N, H, W, Cin, device=DEV)
+    xp = torch.zeros(N, H, W, Cx, device=DEV)
+    xp[..., :Cin] = x
+    xq = xp.to(dtype).requires_grad_(Cx == Cin)
+    w = (torch.randn(Cout, Cin, k, k, device=DEV) / (Cin * k * k) ** 0.5).contiguous(
+        memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(Cout, device=DEV).requires_grad_(True) if bias_relu else None
+    y = F.conv2d(xq, w, b, s, p, relu=bias_relu, needs_input_grad=(Cx == Cin))
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+
+    xr = xq.detach().float()[..., :Cin].permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True) if b is not None else None
+    yr = TF.conv2d(xr, wr, br, s, p)
+    if bias_relu:
+        yr = TF.relu(yr)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    K = Cin * k * k
+    _close(y.permute(0, 3, 1, 2), yr, dtype, what="fprop")
+    if Cx == Cin:
+        _close(xq.grad.permute(0, 3, 1, 2), xr.grad, dtype, scale=1.0, what="dgrad")
+    # wgrad sums over N*OH*OW products
+    _close(w.grad, wr.grad, dtype, scale=1.0, what="wgrad")
+    if b is not None:
+        _close(b.grad, br.grad, dtype, scale=1.0, what="bias grad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_stats_epilogue(dtype):
+    torch.manual_seed(1)
+    x = torch.randn(6, 14, 14, 64, device=DEV).to(dtype)
+    w = (torch.randn(128, 64, 3, 3, device=DEV) / 24).contiguous(memory_format=torch.channels_last)
+    y, stats = F.conv2d(x, w, None, 1, 1, want_stats=True)
+    s = stats.sum(0)
+    yf = y.float().reshape(-1, 128)
+    _close(s[0], yf.sum(0), torch.float32, scale=10, what="sum")
+    _close(s[1], (yf * yf).sum(0), torch.float32, scale=10, what="sumsq")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 96, 2048])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batch_norm(dtype, C, relu, res):
+    torch.manual_seed(2)
+    N, H, W = 4, 7, 9
+    x = (torch.randn(N, H, W, C, device=DEV) * 2 + 0.5).to(dtype).requires_grad_(True)
+    r = torch.randn(N, H, W, C, device=DEV).to(dtype).requires_grad_(True) if res else None
+    g = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True)
+    b = torch.randn(C, device=DEV).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    y = F.batch_norm(x, g, b, rm, rv, nbt, True, 0.1, 1e-5, relu=relu, residual=r)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    rr = r.detach().float().permute(0, 3, 1, 2).requires_grad_(True) if res else None
+    gr, br = g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yr = TF.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = TF.relu(yr)
+    # the kernel masks with the ROUNDED output; do the same in the reference for low precision
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype, what="y")
+    _close(rm, rm2, torch.float32, what="running_mean")
+    _close(rv, rv2, torch.float32, scale=5, what="running_var")
+    assert int(nbt.item()) == 1
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype, scale=2, what="dx")
+    _close(g.grad, gr.grad, dtype, scale=4, what="dgamma")
+    _close(b.grad, br.grad, dtype, scale=4, what="dbeta")
+    if res:
+        _close(r.grad.permute(0, 3, 1, 2), rr.grad, dtype, what="dres")
+
+
+def test_batch_norm_eval():
+    torch.manual_seed(3)
+    C = 64
+    x = torch.randn(2, 5, 5, C, device=DEV).requires_grad_(True)
+    g, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    rm, rv = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
+    y = F.batch_norm(x, g, b, rm, rv, None, False, 0.1, 1e-5, relu=True)
+    y.sum().backward()
+    xr = x.detach().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = TF.relu(TF.batch_norm(xr, rm, rv, g, b, False, 0.1, 1e-5))
+    yr.sum().backward()
+    _close(y.permute(0, 3, 1, 2), yr, torch.float32)
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,s,p,H", [(3, 2, 1, 16), (3, 2, 0, 13), (2, 2, 0, 8)])
+def test_max_pool(dtype, k, s, p, H):
+    torch.manual_seed(4)
+    x = torch.randn(3, H, H, 64, device=DEV).to(dtype).requires_grad_(True)
+    y = F.max_pool2d(x, k, s, p)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = TF.max_pool2d(xr, k, s, p)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype)
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,o", [(7, 1), (13, 6), (10, 7)])
+def test_avg_pool(dtype, H, o):
+    torch.manual_seed(5)
+    x = torch.randn(3, H, H, 64, device=DEV).to(dtype).requires_grad_(True)
+    y = F.adaptive_avg_pool2d(x, o)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = TF.adaptive_avg_pool2d(xr, o)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype)
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,I,O,relu", [(32, 2048, 1000, False), (16, 512, 10, False), (24, 256, 4096, True)])
+def test_linear(dtype, M, I, O, relu):
+    torch.manual_seed(6)
+    x = torch.randn(M, I, device=DEV).to(dtype).requires_grad_(True)
+    w = (torch.randn(O, I, device=DEV) / I ** 0.5).requires_grad_(True)
+    b = torch.randn(O, device=DEV).requires_grad_(True)
+    y = F.linear(x, w, b, relu=relu, out_dtype=torch.float32)
+    gy = torch.randn(M, O, device=DEV)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    yr = TF.linear(xr, wr, br)
+    if relu:
+        yr = TF.relu(yr)
+    yr.backward(gy.to(dtype).float() if dtype != torch.float32 else gy)
+    _close(y, yr, dtype, what="y")
+    _close(x.grad, xr.grad, dtype, scale=2, what="dx")
+    _close(w.grad, wr.grad, dtype, scale=2, what="dw")
+    _close(b.grad, br.grad, dtype, scale=2, what="db")
+
+
+@pytest.mark.parametrize("C", [1000, 10])
+def test_cross_entropy_and_metrics(C):
+    torch.manual_seed(7)
+    N = 37
+    z = (torch.randn(N, C, device=DEV) * 3).requires_grad_(True)
+    t = torch.randint(0, C, (N,), device=DEV)
+    loss, rec = F.loss_and_metrics(z, t)
+    (loss * 3.0).backward()
+    zr = z.detach().clone().requires_grad_(True)
+    lr = TF.cross_entropy(zr, t)
+    (lr * 3.0).backward()
+    _close(loss, lr, torch.float32)
+    _close(z.grad, zr.grad, torch.float32)
+    top = zr.detach().topk(min(5, C), 1).indices
+    c1 = (top[:, 0] == t).sum().item()
+    c5 = (top == t[:, None]).any(1).sum().item()
+    rec = rec.cpu()
+    assert abs(rec[0].item() - lr.item() * N) < 1e-2
+    assert rec[1].item() == c1 and rec[2].item() == c5 and rec[3].item() == N
+
+
+def test_relu_add_dropout_normalize():
+    torch.manual_seed(8)
+    a = torch.randn(5, 6, 7, 64, device=DEV).requires_grad_(True)
+    b = torch.randn(5, 6, 7, 64, device=DEV).requires_grad_(True)
+    y = F.add_relu(a, b)
+    y.sum().backward()
+    assert torch.equal(y, torch.relu(a + b).detach())
+    assert torch.equal(a.grad, (y > 0).float()) and torch.equal(b.grad, a.grad)
+    r = F.relu(a.detach())
+    assert torch.equal(r, torch.relu(a.detach()))
+    d = F.dropout(torch.ones(1 << 16, device=DEV), 0.5, True)
+    frac = (d == 0).float().mean().item()
+    assert 0.45 < frac < 0.55 and set(d.unique().tolist()) <= {0.0, 2.0}
+    u8 = torch.randint(0, 256, (3, 8, 9, 3), dtype=torch.uint8, device=DEV)
+    n = F.normalize_u8(u8, torch.float32, 8)
+    mean = torch.tensor(F.IMAGENET_MEAN, device=DEV) * 255
+    std = torch.tensor(F.IMAGENET_STD, device=DEV) * 255
+    _close(n[..., :3], (u8.float() - mean) / std, torch.float32)
+    assert n.shape[-1] == 8 and float(n[..., 3:].abs().max()) == 0.0
+    n2 = F.normalize_u8(u8.permute(0, 3, 1, 2).contiguous(), torch.bfloat16, 8, input_layout="nchw")
+    _close(n2[..., :3], (u8.float() - mean) / std, torch.bfloat16)
+    xf = torch.randn(2, 3, 5, 6, device=DEV)
+    h = F.to_nhwc(xf, torch.float32, 8)
+    assert torch.equal(h[..., :3], xf.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("lp", [None, torch.bfloat16])
+def test_fused_sgd_matches_torch(lp):
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.ops import hip_ops
+
+    torch.manual_seed(9)
+    shapes = [(64, 3, 7, 7), (128,), (1000, 512), (5,), (256, 64, 1, 1)]
+    ps = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    ps[0] = ps[0].detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    if lp is not None:
+        hip_ops.linear_weight(ps[2], lp)
+    a = FusedSGD(ps, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    b = torch.optim.SGD(qs, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for step in range(4):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad = g.clone()
+            q.grad = g.clone()
+        a.step()
+        b.step()
+        for p, q in zip(ps, qs):
+            _close(p, q, torch.float32, what="step %d" % step)
+    if lp is not None:
+        assert torch.equal(hip_ops.linear_weight(ps[2], lp), ps[2].detach().to(lp))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    _close(sa["state"][2]["momentum_buffer"], sb["state"][2]["momentum_buffer"], torch.float32)
+
+
+def test_loss_scaler_overflow_skips_step():
+    from distributed_pytorch_amd import amp
+    from distributed_pytorch_amd.optim import FusedSGD
+
+    p = torch.ones(1024, device=DEV).requires_grad_(True)
+    opt = FusedSGD([p], lr=0.1, momentum=0.9)
+    scaler = amp.LossScaler(torch.device(DEV), init_scale=1024.0, dynamic=True, growth_interval=2)
+    p.grad = torch.full_like(p, float("inf"))
+    scaler.check_overflow([p.grad])
+    opt.arm_scaler(scaler)
+    opt.step()
+    assert torch.equal(p.detach(), torch.ones_like(p)) and scaler.loss_scale() == 512.0
+    for _ in range(2):
+        p.grad = torch.full_like(p, 512.0)
+        scaler.check_overflow([p.grad])
+        opt.arm_scaler(scaler)
+        opt.step()
+    assert scaler.loss_scale() == 1024.0
+    assert abs(p.detach()[0].item() - (1 - 0.1 * 1 - 0.1 * 1.9)) < 1e-5
