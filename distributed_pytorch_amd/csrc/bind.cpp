@@ -106,20 +106,20 @@ PYBIND11_MODULE(_C, m) {
   });
   m.def("bn_bwd_apply", [](uintptr_t dy, uintptr_t x, uintptr_t y, uintptr_t dx, uintptr_t dres, long M, int C,
                            int dtype, uintptr_t mean, uintptr_t invstd, uintptr_t gamma, uintptr_t dgamma,
-                           uintptr_t dbeta, double count, uintptr_t count_dev, int relu, uintptr_t s) {
+                           uintptr_t dbeta, double count, uintptr_t count_dev, uintptr_t coef, int relu, uintptr_t s) {
     bn_bwd_apply_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const void>(y), ptr<void>(dx), ptr<void>(dres), M,
                         C, dtype, ptr<const float>(mean), ptr<const float>(invstd), ptr<const float>(gamma),
-                        ptr<const float>(dgamma), ptr<const float>(dbeta), count, ptr<const float>(count_dev), relu, st(s));
+                        ptr<const float>(dgamma), ptr<const float>(dbeta), count, ptr<const float>(count_dev), ptr<float>(coef), relu, st(s));
   });
 
   // ---- pooling
-  m.def("maxpool_fwd", [](uintptr_t x, uintptr_t y, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw,
+  m.def("maxpool_fwd", [](uintptr_t x, uintptr_t y, uintptr_t idx, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw,
                           int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
-    maxpool_fwd_launch(ptr<const void>(x), ptr<void>(y), NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype, st(s));
+    maxpool_fwd_launch(ptr<const void>(x), ptr<void>(y), ptr<uint8_t>(idx), NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype, st(s));
   });
   m.def("maxpool_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, int NB, int IH, int IW, int C, int OH, int OW,
                           int kh, int kw, int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
-    maxpool_bwd_launch(ptr<const void>(x), ptr<const void>(dy), ptr<void>(dx), NB, IH, IW, C, OH, OW, kh, kw, sh, sw,
+    maxpool_bwd_launch(ptr<const uint8_t>(x), ptr<const void>(dy), ptr<void>(dx), NB, IH, IW, C, OH, OW, kh, kw, sh, sw,
                        ph, pw, dtype, st(s));
   });
   m.def("avgpool_fwd", [](uintptr_t x, uintptr_t y, int NB, int IH, int IW, int C, int OH, int OW, int dtype,

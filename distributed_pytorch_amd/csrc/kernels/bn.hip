@@ -179,6 +179,18 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   }
 }
 
+// Per-channel coefficient vectors are loop-invariant for a thread whenever the grid stride is a
+// multiple of the chunk-column count (always true for power-of-two channel counts): they are then
+// loaded ONCE into registers instead of per element.
+template <int VEC>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, float (&v)[VEC]) {
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) {
+    const float4 a = reinterpret_cast<const float4*>(p + c0)[q];
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, long nchunks, int cc,
@@ -186,20 +198,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ shift, int relu) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
-    const int c0 = (int)(i % cc) * VEC;
+  const bool fixed = (stride % cc) == 0;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float scv[VEC], shv[VEC];
+  int c0 = (int)(i % cc) * VEC;
+  load_coef<VEC>(scale, c0, scv);
+  load_coef<VEC>(shift, c0, shv);
+  for (; i < nchunks; i += stride) {
+    if (!fixed) {
+      c0 = (int)(i % cc) * VEC;
+      load_coef<VEC>(scale, c0, scv);
+      load_coef<VEC>(shift, c0, shv);
+    }
     Vec16<T> vx, vr, vo;
     vx.load(x + i * VEC);
     if (res != nullptr) vr.load(res + i * VEC);
-    const float4* sc = reinterpret_cast<const float4*>(scale + c0);
-    const float4* sh = reinterpret_cast<const float4*>(shift + c0);
-    float scv[VEC], shv[VEC];
-#pragma unroll
-    for (int q = 0; q < VEC / 4; ++q) {
-      const float4 a = sc[q], b = sh[q];
-      scv[4 * q] = a.x; scv[4 * q + 1] = a.y; scv[4 * q + 2] = a.z; scv[4 * q + 3] = a.w;
-      shv[4 * q] = b.x; shv[4 * q + 1] = b.y; shv[4 * q + 2] = b.z; shv[4 * q + 3] = b.w;
-    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float v = vx.get(j) * scv[j] + shv[j];
@@ -211,35 +224,53 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// coef[0] = A, coef[1] = B, coef[2] = K with dx = A*dy_m + B*x + K  (dy_m = ReLU-masked dy):
+//   A = gamma*invstd, B = -A*invstd*sum(dy*xhat)/count, K = -A*sum(dy)/count - B*mean
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     const float* __restrict__ gamma, float inv_count,
+                                     const float* __restrict__ count_dev, int C, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (count_dev != nullptr) inv_count = 1.f / count_dev[0];
+  const float is = invstd[c], g = gamma ? gamma[c] : 1.f;
+  const float A = g * is;
+  const float B = -A * is * dgamma[c] * inv_count;
+  coef[c] = A;
+  coef[C + c] = B;
+  coef[2 * C + c] = -A * dbeta[c] * inv_count - B * mean[c];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, T* __restrict__ dx,
-                                                           T* __restrict__ dres, long nchunks, int cc,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, float inv_count,
-                                                           const float* __restrict__ count_dev, int relu) {
+                                                           T* __restrict__ dres, long nchunks, int cc, int C,
+                                                           const float* __restrict__ coef, int relu) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  if (count_dev != nullptr) inv_count = 1.f / count_dev[0];
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
-    const int c0 = (int)(i % cc) * VEC;
+  const bool fixed = (stride % cc) == 0;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float ca[VEC], cb[VEC], ck[VEC];
+  int c0 = (int)(i % cc) * VEC;
+  load_coef<VEC>(coef, c0, ca);
+  load_coef<VEC>(coef + C, c0, cb);
+  load_coef<VEC>(coef + 2 * C, c0, ck);
+  for (; i < nchunks; i += stride) {
+    if (!fixed) {
+      c0 = (int)(i % cc) * VEC;
+      load_coef<VEC>(coef, c0, ca);
+      load_coef<VEC>(coef + C, c0, cb);
+      load_coef<VEC>(coef + 2 * C, c0, ck);
+    }
     Vec16<T> vd, vx, vy, vo, vr;
     vd.load(dy + i * VEC);
     vx.load(x + i * VEC);
     if (relu) vy.load(y + i * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const int c = c0 + j;
       float d = vd.get(j);
       if (relu && !(vy.get(j) > 0.f)) d = 0.f;
-      const float is = invstd[c];
-      const float xh = (vx.get(j) - mean[c]) * is;
-      const float g = gamma ? gamma[c] : 1.f;
-      const float v = g * is * (d - dbeta[c] * inv_count - xh * dgamma[c] * inv_count);
-      vo.set(j, v);
+      vo.set(j, ca[j] * d + cb[j] * vx.get(j) + ck[j]);
       vr.set(j, d);
     }
     vo.store(dx + i * VEC);
@@ -357,25 +388,17 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
 void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
                          int C, int dtype, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, double count,
-                         const float* count_dev, int relu, hipStream_t s) {
+                         const float* count_dev, float* coef, int relu, hipStream_t s) {
   check_c(C, dtype);
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, dgamma, dbeta, mean, invstd,
+                     gamma, (float)(1.0 / count), count_dev, C, coef);
   const int grid = grid_for(nchunks);
-  const float ic = (float)(1.0 / count);
-  if (dtype == kF32)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy,
-                       (const float*)x, (const float*)y, (float*)dx, (float*)dres, nchunks, C / vec, mean,
-                       invstd, gamma, dgamma, dbeta, ic, count_dev, relu);
-  else if (dtype == kBF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)dx, (bf16_t*)dres, nchunks, C / vec, mean,
-                       invstd, gamma, dgamma, dbeta, ic, count_dev, relu);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)dy,
-                       (const f16_t*)x, (const f16_t*)y, (f16_t*)dx, (f16_t*)dres, nchunks, C / vec, mean,
-                       invstd, gamma, dgamma, dbeta, ic, count_dev, relu);
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)dy,
+                                               (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
+                                               coef, relu));
   DPA_CHECK_HIP(hipGetLastError());
 }
 

@@ -71,12 +71,14 @@ void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgam
 void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
                          int C, int dtype, const float* mean, const float* invstd,
                          const float* gamma, const float* dgamma, const float* dbeta, double count,
-                         const float* count_dev, int relu, hipStream_t s);
+                         const float* count_dev, float* coef /* fp32 workspace [3][C] */, int relu,
+                         hipStream_t s);
 
 // ------------------------------------------------------------------------------ pool.hip
-void maxpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,
+// idx (optional, uint8 per output element): tap code r*kw+q of the first arg-max, consumed by backward
+void maxpool_fwd_launch(const void* x, void* y, uint8_t* idx, int NB, int IH, int IW, int C, int OH, int OW,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
-void maxpool_bwd_launch(const void* x, const void* dy, void* dx, int NB, int IH, int IW, int C,
+void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, int IH, int IW, int C,
                         int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
                         hipStream_t s);
 void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,

@@ -14,8 +14,8 @@ struct PoolGeom {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolGeom g,
-                                                          long total) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, PoolGeom g, long total) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int cc = g.C / VEC;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -26,8 +26,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     const int oy = (int)(pix % g.OH);
     const int n = (int)(pix / g.OH);
     float m[VEC];
+    int am[VEC];   // first arg-max in scan order (torch semantics), as the tap code r*kw + q
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+    for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = 255; }
     for (int r = 0; r < g.kh; ++r) {
       const int iy = oy * g.sh - g.ph + r;
       if ((unsigned)iy >= (unsigned)g.IH) continue;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float f = v.get(j);
-          m[j] = (f > m[j] || f != f) ? f : m[j];
+          if (f > m[j] || f != f || am[j] == 255) { m[j] = f; am[j] = r * g.kw + q; }
         }
       }
     }
@@ -47,11 +48,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o.set(j, m[j]);
     o.store(y + i * VEC);
+    if (idx != nullptr) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) idx[i * VEC + j] = (uint8_t)am[j];
+    }
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
                                                           T* __restrict__ dx, PoolGeom g, long total) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int cc = g.C / VEC;
@@ -72,33 +77,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     const int ox_hi = min(g.OW - 1, (ix + g.pw) / g.sw);
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        // first arg-max of the window in scan order (torch semantics)
-        float m[VEC];
-        int am[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = -1; }
-        for (int r = 0; r < g.kh; ++r) {
-          const int yy = oy * g.sh - g.ph + r;
-          if ((unsigned)yy >= (unsigned)g.IH) continue;
-          for (int q = 0; q < g.kw; ++q) {
-            const int xx = ox * g.sw - g.pw + q;
-            if ((unsigned)xx >= (unsigned)g.IW) continue;
-            Vec16<T> v;
-            v.load(x + (((size_t)n * g.IH + yy) * g.IW + xx) * g.C + c * VEC);
-            const int id = yy * g.IW + xx;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-              const float f = v.get(j);
-              if (f > m[j] || f != f || am[j] < 0) { m[j] = f; am[j] = id; }
-            }
-          }
-        }
+        const int code = (iy - (oy * g.sh - g.ph)) * g.kw + (ix - (ox * g.sw - g.pw));
+        const size_t o = (((size_t)n * g.OH + oy) * g.OW + ox) * g.C + c * VEC;
         Vec16<T> d;
-        d.load(dy + (((size_t)n * g.OH + oy) * g.OW + ox) * g.C + c * VEC);
-        const int me = iy * g.IW + ix;
+        d.load(dy + o);
+        uint8_t am[VEC];
+        if (VEC == 8) *reinterpret_cast<uint2*>(am) = *reinterpret_cast<const uint2*>(idx + o);
+        else *reinterpret_cast<uint32_t*>(am) = *reinterpret_cast<const uint32_t*>(idx + o);
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-          if (am[j] == me) acc[j] += d.get(j);
+          if (am[j] == code) acc[j] += d.get(j);
       }
     Vec16<T> o;
 #pragma unroll
@@ -188,24 +176,24 @@ inline void check_c(int C, int dtype) {
 
 }  // namespace
 
-void maxpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw,
+void maxpool_fwd_launch(const void* x, void* y, uint8_t* idx, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw,
                         int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
   check_c(C, dtype);
   PoolGeom g{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
   const long total = (long)NB * OH * OW * (C / (dtype == kF32 ? 4 : 8));
   if (total <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
-                                               (const T*)x, (T*)y, g, total));
+                                               (const T*)x, (T*)y, idx, g, total));
   DPA_CHECK_HIP(hipGetLastError());
 }
-void maxpool_bwd_launch(const void* x, const void* dy, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
+void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
                         int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
   check_c(C, dtype);
   PoolGeom g{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
   const long total = (long)NB * IH * IW * (C / (dtype == kF32 ? 4 : 8));
   if (total <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
-                                               (const T*)x, (const T*)dy, (T*)dx, g, total));
+                                               idx, (const T*)dy, (T*)dx, g, total));
   DPA_CHECK_HIP(hipGetLastError());
 }
 void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW, int dtype,

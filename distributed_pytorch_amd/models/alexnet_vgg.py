@@ -51,7 +51,7 @@ def run_fused_sequential(seq: nn.Sequential, x, final_dtype=None):
 class _ImageNetCNN(nn.Module):
     def prepare_input(self, x):
         dtype = amp.compute_dtype(torch.float32)
-        pad = STEM_PAD_C if x.is_cuda else 0
+        pad = STEM_PAD_C if F._on_gpu(x) else 0
         if x.dtype == torch.uint8:
             layout = "nhwc" if x.shape[-1] in (1, 3) else "nchw"
             return F.normalize_u8(x, dtype, pad, input_layout=layout)

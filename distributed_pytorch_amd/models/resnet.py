@@ -127,7 +127,7 @@ class ResNet(nn.Module):
         """Accepts torchvision-style float NCHW, or uint8 (NHWC/NCHW) straight from
         the prefetcher; returns normalised NHWC in the compute dtype."""
         dtype = amp.compute_dtype(torch.float32)
-        pad = STEM_PAD_C if x.is_cuda else 0
+        pad = STEM_PAD_C if F._on_gpu(x) else 0
         if x.dtype == torch.uint8:
             layout = "nhwc" if x.shape[-1] in (1, 3) else "nchw"
             return F.normalize_u8(x, dtype, pad, input_layout=layout)

@@ -169,7 +169,7 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool = True, residual=No
     """conv -> BN(+residual)(+ReLU).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
     re-read for statistics."""
-    fuse = x.is_cuda and bn.training and bn.process_group is None
+    fuse = F._on_gpu(x) and bn.training and bn.process_group is None
     if fuse:
         y, stats = conv(x, want_stats=True)
         return bn(y, relu=relu, residual=residual, stats=stats)

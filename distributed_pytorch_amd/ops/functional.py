@@ -16,8 +16,16 @@ import torch
 import torch.nn.functional as TF
 
 
+import os as _os
+
+# DPA_TORCH_BASELINE=1 routes GPU tensors through the stock PyTorch ops below (MIOpen / rocBLAS /
+# ATen).  It exists ONLY to measure the "stock PyTorch-ROCm" baseline of BASELINE.md on the same
+# model definition; the framework never takes this path by itself.
+_TORCH_BASELINE = _os.environ.get("DPA_TORCH_BASELINE", "0") == "1"
+
+
 def _on_gpu(t: torch.Tensor) -> bool:
-    return t.is_cuda
+    return t.is_cuda and not _TORCH_BASELINE
 
 
 def _hip():
@@ -204,8 +212,8 @@ def normalize_u8(x: torch.Tensor, dtype: torch.dtype = torch.float32, pad_c: int
         return _hip().normalize_u8(x, dtype, pad_c, mean, std, input_layout)
     if input_layout == "nchw":
         x = x.permute(0, 2, 3, 1)
-    m = torch.tensor(mean, dtype=torch.float32) * 255.0
-    s = torch.tensor(std, dtype=torch.float32) * 255.0
+    m = torch.tensor(mean, dtype=torch.float32, device=x.device) * 255.0
+    s = torch.tensor(std, dtype=torch.float32, device=x.device) * 255.0
     y = ((x.float() - m) / s).to(dtype)
     if pad_c and pad_c > y.shape[-1]:
         y = TF.pad(y, (0, pad_c - y.shape[-1]))

@@ -457,9 +457,10 @@ class _BNFn(torch.autograd.Function):
         g32 = _f32(weight.detach())
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
+        wk = torch.empty((3, Cc), dtype=torch.float32, device=dev)
         C().bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), _p(dres), M, Cc, _dt(x),
                          coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), gsums[0].data_ptr(),
-                         gsums[1].data_ptr(), count, _p(count_dev), 1 if relu else 0, st)
+                         gsums[1].data_ptr(), count, _p(count_dev), wk.data_ptr(), 1 if relu else 0, st)
         dgamma = sums[0].to(weight.dtype) if ctx.needs_input_grad[1] else None
         dbeta = sums[1].to(weight.dtype) if ctx.needs_input_grad[2] else None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
@@ -524,21 +525,24 @@ class _MaxPoolFn(torch.autograd.Function):
         NB, IH, IW, Cc = x.shape
         OH, OW = _conv_out(IH, k[0], s[0], p[0]), _conv_out(IW, k[1], s[1], p[1])
         y = torch.empty((NB, OH, OW, Cc), dtype=x.dtype, device=x.device)
-        C().maxpool_fwd(x.data_ptr(), y.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1],
-                        _dt(x), _stream())
-        ctx.save_for_backward(x)
-        ctx.cfg = (k, s, p, OH, OW)
+        if k[0] * k[1] > 250:
+            raise ValueError("max_pool2d: window too large")
+        idx = torch.empty((NB, OH, OW, Cc), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        C().maxpool_fwd(x.data_ptr(), y.data_ptr(), _p(idx), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
+                        p[0], p[1], _dt(x), _stream())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (k, s, p, OH, OW, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        k, s, p, OH, OW = ctx.cfg
+        (idx,) = ctx.saved_tensors
+        k, s, p, OH, OW, xshape = ctx.cfg
         dy = dy if dy.is_contiguous() else dy.contiguous()
-        NB, IH, IW, Cc = x.shape
-        dx = torch.empty_like(x)
-        C().maxpool_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
-                        p[0], p[1], _dt(x), _stream())
+        NB, IH, IW, Cc = xshape
+        dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device)
+        C().maxpool_bwd(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
+                        p[0], p[1], _dt(dy), _stream())
         return dx, None, None, None
 
 

@@ -77,7 +77,9 @@ class FusedSGD(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         scaler, self._scaler = self._scaler, None
-        any_cuda = any(p.is_cuda for g in self.param_groups for p in g["params"])
+        from .ops import functional as _F
+
+        any_cuda = not _F._TORCH_BASELINE and any(p.is_cuda for g in self.param_groups for p in g["params"])
         if any_cuda:
             self._step_hip(scaler)
         else:

@@ -1,0 +1,78 @@
+"""End-to-end parity: the same model / weights / batch on the CPU reference backend (plain PyTorch
+ops) and on the HIP kernel backend must give the same logits, loss and parameter gradients."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, x, t):
+    from distributed_pytorch_amd.ops import functional as F
+
+    model.train()
+    out = model(x)
+    loss, rec = F.loss_and_metrics(out, t)
+    model.zero_grad()
+    loss.backward()
+    return out.detach().float().cpu(), float(loss), {n: p.grad.detach().float().cpu()
+                                                     for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("arch,size,tol", [("resnet18", 64, 2e-3), ("resnet50", 128, 3e-3), ("alexnet", 224, 2e-3),
+                                           ("vgg11_bn", 128, 3e-3)])
+def test_fp32_model_matches_cpu_reference(arch, size, tol):
+    from distributed_pytorch_amd import amp, models
+
+    amp.state().reset()
+    torch.manual_seed(0)
+    cpu = models.create_model(arch, num_classes=1000)
+    for m in cpu.modules():                      # no dropout noise in the comparison
+        if m.__class__.__name__ == "Dropout":
+            m.p = 0.0
+    gpu = copy.deepcopy(cpu).cuda()
+    x = torch.randn(4, 3, size, size)
+    t = torch.randint(0, 1000, (4,))
+    o1, l1, g1 = _run(cpu, x, t)
+    o2, l2, g2 = _run(gpu, x.cuda(), t.cuda())
+    assert abs(l1 - l2) < tol * max(1.0, abs(l1)), (l1, l2)
+    assert (o1 - o2).abs().max() < tol * max(1.0, o1.abs().max())
+    # per-parameter relative L2 error (tiny-batch BatchNorm backward amplifies rounding, so a max-norm
+    # criterion on single entries is not meaningful)
+    # (a conv bias in front of a BatchNorm has an exactly-zero gradient: floor the denominator)
+    floor = 1e-4 * max(g.norm().item() / g.numel() ** 0.5 for g in g1.values())
+    for n in g1:
+        a, b = g1[n], g2[n]
+        rel = ((a - b).norm() / max(a.norm().item(), floor * a.numel() ** 0.5)).item()
+        assert rel < 10 * tol, (n, rel)
+
+
+def test_bf16_training_reduces_loss_and_tracks_fp32():
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.ops import functional as F
+    from distributed_pytorch_amd.optim import FusedSGD
+
+    torch.manual_seed(0)
+    x = torch.randint(0, 256, (16, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    t = torch.randint(0, 10, (16,), device="cuda")
+    curves = {}
+    for level in ("O0", "O2"):
+        torch.manual_seed(1)
+        amp.state().reset()
+        model = models.create_model("resnet18", num_classes=16).cuda().train()
+        opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        model, opt = amp.initialize(model, opt, opt_level=level, dtype="bf16")
+        losses = []
+        for _ in range(12):
+            loss, _ = F.loss_and_metrics(model(x), t)
+            opt.zero_grad()
+            with amp.scale_loss(loss, opt) as s:
+                s.backward()
+            opt.step()
+            losses.append(float(loss))
+        curves[level] = losses
+    amp.state().reset()
+    assert curves["O0"][-1] < 0.5 * curves["O0"][0], curves["O0"]
+    assert curves["O2"][-1] < 0.5 * curves["O2"][0], curves["O2"]
+    assert abs(curves["O0"][0] - curves["O2"][0]) < 0.1
