@@ -52,7 +52,7 @@ def model_state(model: torch.nn.Module, distributed: bool) -> "OrderedDict[str, 
         t = v.detach()
         if t.is_floating_point() and t.dtype != torch.float32:
             t = t.float()
-        sd[k] = t.clone()
+        sd[k] = t.contiguous().clone()      # plain OIHW in the file, whatever the compute layout
     return add_prefix(sd) if distributed else sd
 
 

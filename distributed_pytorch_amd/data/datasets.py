@@ -67,7 +67,7 @@ def fast_collate(batch, memory_format=torch.contiguous_format, nhwc: bool = Fals
         out = torch.zeros((len(imgs), 3, h, w), dtype=torch.uint8).contiguous(
             memory_format=memory_format)
     for i, img in enumerate(imgs):
-        arr = np.asarray(img, dtype=np.uint8)
+        arr = np.array(img, dtype=np.uint8)
         if arr.ndim < 3:
             arr = np.repeat(arr[:, :, None], 3, axis=2)
         if nhwc:

@@ -95,6 +95,20 @@ def shutdown() -> None:
 
 
 # ----------------------------------------------------------------------------- supervisor
+def rank_registry() -> str:
+    """Directory of pid files of live ranks on this node (read by scripts/process_cleanup.sh)."""
+    d = os.path.join(os.environ.get("DPA_RUN_DIR", "/tmp"), "dpa_ranks_%d" % os.getuid())
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _register(pid: int) -> str:
+    path = os.path.join(rank_registry(), str(pid))
+    with open(path, "w") as f:
+        f.write(" ".join(sys.argv))
+    return path
+
+
 def _child(fn: Callable, local_rank: int, nprocs: int, args: tuple, err_q) -> None:
     os.environ["LOCAL_RANK"] = str(local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -129,6 +143,7 @@ def spawn(fn: Callable, nprocs: int, args: tuple = (), poll_s: float = 0.2,
         p = ctx.Process(target=_child, args=(fn, lr, nprocs, args, err_q), daemon=False)
         p.start()
         procs.append(p)
+    pidfiles = [_register(p.pid) for p in procs]
     failed: Optional[Tuple[int, int]] = None
     try:
         alive = set(range(nprocs))
@@ -156,6 +171,11 @@ def spawn(fn: Callable, nprocs: int, args: tuple = (), poll_s: float = 0.2,
                 if p.is_alive():
                     os.kill(p.pid, signal.SIGKILL)
                     p.join(1.0)
+    for f in pidfiles:
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
     if failed is not None:
         tb = ""
         while not err_q.empty():

@@ -18,6 +18,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from .. import backend
+from . import grad_sink
 
 _C = None
 
@@ -241,6 +242,26 @@ def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
     return s1
 
 
+def _flat_same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    if a.shape != b.shape:
+        return False
+    sa = [st for st, n in zip(a.stride(), a.shape) if n > 1]
+    sb = [st for st, n in zip(b.stride(), b.shape) if n > 1]
+    return sa == sb
+
+
+def _deliver(param, g):
+    """Hand a finished parameter gradient to its sink (returns None) or to autograd (returns g)."""
+    s = grad_sink.sink_of(param)
+    if s is None or g is None:
+        return g
+    if not _flat_same_layout(g, s.view):
+        g = torch.empty_like(s.view).copy_(g)
+    C().axpby(g.data_ptr(), _dt(g), s.view.data_ptr(), g.numel(), 1.0, s.beta(), _stream())
+    s.delivered()
+    return None
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad):
@@ -266,6 +287,7 @@ class _ConvFn(torch.autograd.Function):
         _igemm(x, wc, y, bias_f, stats, taps, M, K, Cx, R * S, Cx, R * S * Cx, K, IH, IW, sh, sw, OH, OW,
                relu=relu, dtype=x.dtype, out_dtype=x.dtype)
         ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, y if relu else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -292,7 +314,8 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.view(M, K)).to(ctx.saved_tensors[1].dtype)
+            bias_p = ctx.bias_ref
+            db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
         return dx, dw, db, None, None, None, None, None
 
 
@@ -336,6 +359,13 @@ def conv_wgrad(dy, x, weight, stride, padding):
     C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
               sh, sw, OH, OW, splits, pps, _dt(dy), st)
     gdtype = weight.dtype
+    sink = grad_sink.sink_of(weight)
+    if Cx == Cw and sink is not None and _flat_same_layout(sink.view, weight) \
+            and (weight.is_contiguous(memory_format=torch.channels_last) or R * S == 1):
+        # the slab fold writes the gradient straight into the parameter's bucket view
+        C().slab_reduce(slab.data_ptr(), splits, K * Ktot, sink.view.data_ptr(), _dt(gdtype), sink.beta(), st)
+        sink.delivered()
+        return None
     if Cx == Cw:
         g = torch.empty((K, R, S, Cw), dtype=gdtype, device=dy.device)
         C().slab_reduce(slab.data_ptr(), splits, K * Ktot, g.data_ptr(), _dt(gdtype), 0.0, st)
@@ -345,7 +375,7 @@ def conv_wgrad(dy, x, weight, stride, padding):
         g = torch.empty((K, R, S, Cw), dtype=gdtype, device=dy.device)
         # drop the padded channels: "NCHW -> NHWC" over K*R*S one-pixel images keeps the first Cw of Cx
         _slice_channels(full, g, Cw)
-    return g.permute(0, 3, 1, 2)       # logical [K, C, R, S] with channels_last strides
+    return _deliver(weight, g.permute(0, 3, 1, 2))       # logical [K, C, R, S] with channels_last strides
 
 
 def _slice_channels(src: torch.Tensor, dst: torch.Tensor, keep: int) -> None:
@@ -431,6 +461,7 @@ class _BNFn(torch.autograd.Function):
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
                      coef[3].data_ptr(), 1 if relu else 0, st)
         ctx.save_for_backward(x, y if relu else None, weight, coef, count_dev)
+        ctx.bias_ref = bias
         ctx.cfg = (relu, residual is not None, group, count)
         return y
 
@@ -448,21 +479,36 @@ class _BNFn(torch.autograd.Function):
         C().bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), _p(y), M, Cc, _dt(x), coef[0].data_ptr(),
                           coef[1].data_ptr(), 1 if relu else 0, part.data_ptr(), nblk, st)
         part = _fold(part, Cc)
-        sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)     # [dgamma, dbeta] local
-        C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, sums[0].data_ptr(), sums[1].data_ptr(), st)
-        gsums = sums
+        # local [dgamma, dbeta]: written straight into the parameters' gradient views when possible
+        bias_p = ctx.bias_ref
+        sw_, sb_ = grad_sink.sink_of(weight), grad_sink.sink_of(bias_p)
+        direct = sw_ is not None and sb_ is not None and not sw_.written and not sb_.written \
+            and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        if direct:
+            dg_t, db_t = sw_.view, sb_.view
+        else:
+            sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+            dg_t, db_t = sums[0], sums[1]
+        C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, dg_t.data_ptr(), db_t.data_ptr(), st)
+        gdg, gdb = dg_t, db_t
         if _group_size(group) > 1:
-            gsums = sums.clone()
-            _all_reduce_sum(gsums, group)
+            gs = torch.stack([dg_t, db_t])
+            _all_reduce_sum(gs, group)
+            gdg, gdb = gs[0], gs[1]
         g32 = _f32(weight.detach())
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         wk = torch.empty((3, Cc), dtype=torch.float32, device=dev)
         C().bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), _p(dres), M, Cc, _dt(x),
-                         coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), gsums[0].data_ptr(),
-                         gsums[1].data_ptr(), count, _p(count_dev), wk.data_ptr(), 1 if relu else 0, st)
-        dgamma = sums[0].to(weight.dtype) if ctx.needs_input_grad[1] else None
-        dbeta = sums[1].to(weight.dtype) if ctx.needs_input_grad[2] else None
+                         coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), gdg.data_ptr(),
+                         gdb.data_ptr(), count, _p(count_dev), wk.data_ptr(), 1 if relu else 0, st)
+        if direct:
+            sw_.delivered()
+            sb_.delivered()
+            dgamma = dbeta = None
+        else:
+            dgamma = _deliver(weight, dg_t.to(weight.dtype)) if ctx.needs_input_grad[1] else None
+            dbeta = _deliver(bias_p, db_t.to(bias_p.dtype)) if ctx.needs_input_grad[2] else None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
@@ -695,6 +741,7 @@ class _LinearFn(torch.autograd.Function):
                relu=relu, dtype=x2.dtype, out_dtype=odt)
         y = buf[:, :out_f] if ldc != out_f else buf
         ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.bias_ref = bias
         ctx.cfg = (relu, bias is not None, lead)
         return y.reshape(*lead, out_f) if len(lead) != 1 else y
 
@@ -727,11 +774,19 @@ class _LinearFn(torch.autograd.Function):
             slab = torch.empty((splits, outp, in_f), dtype=torch.float32, device=dy.device)
             C().wgrad(dyp.data_ptr(), x2.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, outp, in_f, 1,
                       outp, in_f, 1, 1, 1, 1, 1, 1, splits, pps, _dt(cdt), st)
-            full = torch.empty((outp, in_f), dtype=weight.dtype, device=dy.device)
-            C().slab_reduce(slab.data_ptr(), splits, outp * in_f, full.data_ptr(), _dt(weight.dtype), 0.0, st)
-            dw = full[:out_f]
+            sink = grad_sink.sink_of(weight)
+            if sink is not None and sink.view.is_contiguous() and outp == out_f:
+                # the slab fold writes the gradient straight into the parameter's bucket view
+                C().slab_reduce(slab.data_ptr(), splits, outp * in_f, sink.view.data_ptr(), _dt(weight.dtype),
+                                sink.beta(), st)
+                sink.delivered()
+            else:
+                full = torch.empty((outp, in_f), dtype=weight.dtype, device=dy.device)
+                C().slab_reduce(slab.data_ptr(), splits, outp * in_f, full.data_ptr(), _dt(weight.dtype), 0.0, st)
+                dw = _deliver(weight, full[:out_f])
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dyp)[:out_f].to(weight.dtype)
+            bias_p = ctx.bias_ref
+            db = _deliver(bias_p, _colsum(dyp)[:out_f].to(bias_p.dtype))
         return dx, dw, db, None, None
 
 

@@ -41,7 +41,7 @@ class FusedSGD(Optimizer):
         self._scaler = None          # armed by amp.scale_loss for the next step
         self._amp_state = None
         self._plan = None            # device chunk table (GPU path)
-        self._flat_grads: List[torch.Tensor] = []   # registered by the gradient arena / DDP
+        self._own_arena = None       # single-GPU gradient arena (a DDP wrapper brings its own)
         self._steps = 0
 
     # ------------------------------------------------------------------ amp hooks
@@ -57,17 +57,50 @@ class FusedSGD(Optimizer):
         self._plan = None
         self.state.clear()
 
-    def register_flat_grads(self, buffers) -> None:
-        self._flat_grads = list(buffers)
+    # ------------------------------------------------------------------ gradient arenas
+    def register_arena(self, arena) -> None:
+        """Kept for API symmetry: arenas are discovered through the parameters' sinks."""
+        self._plan = None
+
+    def _arenas(self):
+        """Gradient arenas behind this optimizer's parameters.  On the GPU every fp32 parameter
+        gets one (DDP's buckets, or a private flat arena on a single GPU) so backward kernels write
+        gradients in place and the device tensor table never changes."""
+        from .ops import functional as _F
+
+        params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not params:
+            return []
+        missing = [p for p in params if getattr(p, "_dpa_sink", None) is None]
+        if missing and not _F._TORCH_BASELINE and all(p.is_cuda and p.dtype == torch.float32 for p in missing):
+            from .parallel.distributed import GradArena
+
+            self._own_arena = GradArena(missing)
+            self._plan = None
+        seen, out = set(), []
+        for p in params:
+            s = getattr(p, "_dpa_sink", None)
+            if s is not None and s.arena is not None and id(s.arena) not in seen:
+                seen.add(id(s.arena))
+                out.append(s.arena)
+        return out
 
     # ------------------------------------------------------------------ zero_grad
     def zero_grad(self, set_to_none: Optional[bool] = None) -> None:
-        """With a gradient arena: one memset per flat bucket (N-K18)."""
-        if self._flat_grads and not set_to_none:
-            for buf in self._flat_grads:
-                buf.zero_()
+        """With a gradient arena nothing is zeroed on the GPU: the first kernel that delivers a
+        gradient overwrites its slot (N-K18); CPU arenas (gloo plumbing) get one memset per bucket."""
+        arenas = self._arenas()
+        if not arenas:
+            super().zero_grad(set_to_none=True if set_to_none is None else set_to_none)
             return
-        super().zero_grad(set_to_none=True if set_to_none is None else set_to_none)
+        for arena in arenas:
+            if arena.params[0].is_cuda and set_to_none is not False:
+                arena.begin_step()
+                for p in arena.params:
+                    p.grad = None
+            else:
+                arena.zero()
+                arena.attach()
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -77,6 +110,8 @@ class FusedSGD(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         scaler, self._scaler = self._scaler, None
+        for arena in self._arenas():
+            arena.finish_step()
         from .ops import functional as _F
 
         any_cuda = not _F._TORCH_BASELINE and any(p.is_cuda for g in self.param_groups for p in g["params"])

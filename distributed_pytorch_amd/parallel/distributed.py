@@ -6,21 +6,27 @@ Capability parity with what the reference gets from
 ``apex.parallel.DistributedDataParallel(model, delay_allreduce=True)``
 (``imagenet_ddp_apex.py:183``), re-designed for one-process-per-MI355X:
 
-* **Gradient arena**: every ``param.grad`` is a *view* into a flat per-bucket
-  buffer, so a bucket is all-reduced in place (no flatten/unflatten copies) and
-  ``zero_grad`` is one memset per bucket.  The arena also exists for world
-  size 1 (single GPU) — only the communication is skipped.
-* **Overlap**: per-parameter post-accumulate hooks count a bucket down; when it
-  completes, the comm stream waits on a compute-stream event and the RCCL
-  all-reduce (mean) is enqueued while backward continues.  An end-of-backward
-  engine callback joins the comm stream back — no host synchronisation.
-* **Bucket order** is re-planned from the observed ready order after the first
-  backward (c10d's rebuild).
-* ``delay_allreduce=True``: one flat bucket per dtype reduced after backward.
-* Init: parameter-shape verification across ranks, then rank-0 broadcast of a
-  flat parameter arena and the (flat) BatchNorm buffer arena (C-c); optional
-  per-forward buffer broadcast (C-d, ``broadcast_buffers``).
-* ``state_dict`` keys carry the ``module.`` prefix like the reference's files.
+* **Gradient arena**: every parameter's gradient lives as a *view* inside a flat per-bucket
+  buffer.  On the GPU the backward kernels (wgrad slab-reduce, BN / bias reductions) write their
+  result STRAIGHT into that view through the parameter's *gradient sink* (``ops/grad_sink.py``):
+  no autograd accumulate pass, no flatten / unflatten copies, no per-step memset, and stable
+  pointers for the fused optimizer's device table.  The arena also serves a single GPU -- only
+  the communication is skipped.
+* **Overlap**: each delivered gradient counts its bucket down; a complete bucket is all-reduced
+  (mean) in place on the communicator's own stream, behind an event recorded on the compute
+  stream, while backward keeps running.  Buckets are issued in index order so every rank
+  enqueues the same collective sequence.  An end-of-backward engine callback joins the comm
+  stream back -- no host synchronisation.  On the GPU this state machine is the C++
+  ``BucketReducer`` calling RCCL directly (``csrc/comm/comm.cpp``); with the ``gloo`` backend
+  (CPU plumbing configuration) the same logic runs in Python over ``torch.distributed``.
+* ``delay_allreduce=True``: one flat bucket per dtype, reduced after backward (Apex mode).
+* Init: parameter-shape verification across ranks, then rank-0 broadcast of the flat parameter
+  and buffer arenas (C-c); optional per-forward buffer broadcast (C-d, ``broadcast_buffers``).
+* ``state_dict`` keys carry the ``module.`` prefix like the reference's checkpoints.
+
+Bucket size: xGMI gives every GPU 7 point-to-point links; collectives are bandwidth-cheap and
+launch-latency-dominated, so buckets default to 64 MiB (ResNet-50's 102 MB of fp32 gradients
+are two collectives) with a small first bucket... the LAST bucket (stem) is the only exposed one.
 """
 from __future__ import annotations
 
@@ -31,8 +37,18 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from ..ops import grad_sink
 from .bucketing import MiB, BucketSpec, chunk_ranges, plan_buckets
 from .comm import TorchComm, default_comm
+
+
+def _param_view(flat: torch.Tensor, off: int, p: torch.Tensor) -> torch.Tensor:
+    """View of ``flat[off: off+numel]`` with the parameter's shape AND memory layout."""
+    v = flat[off:off + p.numel()]
+    if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+        k, c, r, s = p.shape
+        return v.view(k, r, s, c).permute(0, 3, 1, 2)      # logical OIHW over KRSC memory
+    return v.view(p.shape)
 
 
 class _Bucket:
@@ -40,53 +56,46 @@ class _Bucket:
         self.spec = spec
         self.params = params
         self.flat = torch.zeros(spec.total, dtype=dtype, device=device)
-        self.views = []
-        for p, off, n in zip(params, spec.offsets, spec.numels):
-            v = self.flat[off:off + n]
-            if p.dim() == 4:
-                k, c, r, s = p.shape
-                v = v.view(k, r, s, c).permute(0, 3, 1, 2)      # logical OIHW over KRSC memory
-            else:
-                v = v.view(p.shape)
-            self.views.append(v)
+        self.views = [_param_view(self.flat, off, p) for p, off in zip(params, spec.offsets)]
         self.pending = len(params)
         self.launched = False
         self.work = []
 
 
 class GradArena:
-    """Flat gradient buckets + (optional) reducer state machine."""
+    """Flat gradient buckets; installs a gradient sink on every parameter."""
 
-    def __init__(self, params: List[nn.Parameter], cap_bytes: int, first_cap_bytes: int,
-                 order: Optional[List[int]] = None, single_bucket: bool = False):
-        self.params = params
-        n = len(params)
+    def __init__(self, params: List[nn.Parameter], cap_bytes: int = 1 << 62, first_cap_bytes: int = 1 << 62,
+                 order: Optional[List[int]] = None, single_bucket: bool = False, on_ready=None):
+        self.params = list(params)
+        n = len(self.params)
         order = list(range(n - 1, -1, -1)) if order is None else order
-        dtypes = sorted({self.grad_dtype(p) for p in params}, key=str)
-        keys = [dtypes.index(self.grad_dtype(p)) for p in params]
+        dtypes = sorted({p.dtype for p in self.params}, key=str)
+        keys = [dtypes.index(p.dtype) for p in self.params]
         if single_bucket:
             cap_bytes = first_cap_bytes = 1 << 62
-        specs = plan_buckets([p.numel() for p in params],
-                             [torch.empty((), dtype=self.grad_dtype(p)).element_size() for p in params],
+        specs = plan_buckets([p.numel() for p in self.params], [p.element_size() for p in self.params],
                              keys, order, cap_bytes, first_cap_bytes)
         self.buckets: List[_Bucket] = []
         self.bucket_of: Dict[int, int] = {}
+        self.view_of: Dict[int, torch.Tensor] = {}
         for spec in specs:
-            ps = [params[i] for i in spec.param_ids]
+            ps = [self.params[i] for i in spec.param_ids]
             b = _Bucket(spec, ps, ps[0].device, dtypes[spec.dtype_key])
-            for pid in spec.param_ids:
+            for pid, v in zip(spec.param_ids, b.views):
                 self.bucket_of[pid] = len(self.buckets)
+                self.view_of[pid] = v
             self.buckets.append(b)
+        self.sinks = []
+        for pid, p in enumerate(self.params):
+            s = grad_sink.GradSink(p, self.view_of[pid], pid, on_ready, self)
+            p._dpa_sink = s
+            self.sinks.append(s)
         self.attach()
 
-    @staticmethod
-    def grad_dtype(p: torch.Tensor) -> torch.dtype:
-        return p.dtype
-
     def attach(self) -> None:
-        for b in self.buckets:
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+        for pid, p in enumerate(self.params):
+            p.grad = self.view_of[pid]
 
     def flat_buffers(self) -> List[torch.Tensor]:
         return [b.flat for b in self.buckets]
@@ -94,13 +103,110 @@ class GradArena:
     def zero(self) -> None:
         for b in self.buckets:
             b.flat.zero_()
+        self.begin_step(zeroed=True)
+
+    def begin_step(self, zeroed: bool = False) -> None:
+        """New iteration: the first delivery into every sink overwrites (``zeroed`` buckets: adds)."""
+        for s in self.sinks:
+            s.written = False
+            s.zeroed = zeroed
+
+    def finish_step(self) -> None:
+        """Gradient slots nobody wrote this iteration (unused parameters) must read as zero."""
+        for s in self.sinks:
+            if not s.written and not s.zeroed:
+                s.view.zero_()
+                s.zeroed = True
+            if s.param.grad is not s.view:
+                s.param.grad = s.view
+
+
+class _PyReducer:
+    """Python twin of the C++ BucketReducer over a TorchComm (gloo on CPU, ProcessGroupNCCL on GPU)."""
+
+    def __init__(self, ddp, arena: GradArena):
+        self.ddp, self.arena = ddp, arena
+        self.next = 0
+
+    def prepare(self):
+        for b in self.arena.buckets:
+            b.pending, b.launched, b.work = len(b.params), False, []
+        self.next = 0
+
+    def mark_ready(self, pid: int):
+        b = self.arena.buckets[self.arena.bucket_of[pid]]
+        if b.pending <= 0:
+            return
+        b.pending -= 1
+        if b.pending == 0 and not self.ddp.delay_allreduce:
+            self.flush(False)
+
+    def flush(self, force: bool):
+        bs = self.arena.buckets
+        while self.next < len(bs):
+            b = bs[self.next]
+            if b.pending > 0 and not force:
+                break
+            b.pending = 0
+            self._launch(b)
+            self.next += 1
+
+    def _launch(self, b: _Bucket):
+        b.launched = True
+        ddp = self.ddp
+        if ddp.world_size == 1:
+            return
+        nbytes = b.flat.numel() * b.flat.element_size()
+        pieces = [b.flat]
+        if nbytes > ddp.chunk_bytes:
+            pieces = [b.flat[s:e] for s, e in chunk_ranges(b.flat.numel(), b.flat.element_size(), ddp.chunk_bytes)]
+        if ddp.on_gpu and ddp.comm_stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(ddp.device))
+            with torch.cuda.stream(ddp.comm_stream):
+                ddp.comm_stream.wait_event(ready)
+                for piece in pieces:
+                    b.work.append(ddp.comm.all_reduce_mean(piece, async_op=True))
+        else:
+            for piece in pieces:
+                b.work.append(ddp.comm.all_reduce_mean(piece, async_op=True))
+
+    def finalize(self):
+        self.flush(True)
+        for b in self.arena.buckets:
+            for w in b.work:
+                w.wait()                        # GPU: stream-level wait; gloo: host wait
+            b.work = []
+        ddp = self.ddp
+        if ddp.on_gpu and ddp.world_size > 1 and ddp.comm_stream is not None:
+            torch.cuda.current_stream(ddp.device).wait_stream(ddp.comm_stream)
+
+
+class _NativeReducer:
+    """C++ BucketReducer: RCCL all-reduce per bucket on the communicator's stream."""
+
+    def __init__(self, ddp, arena: GradArena):
+        self.ddp, self.arena = ddp, arena
+        pb = [arena.bucket_of[i] for i in range(len(arena.params))]
+        self.raw = ddp.comm.make_reducer(arena.flat_buffers(), pb)
+
+    def prepare(self):
+        self.raw.prepare()
+
+    def mark_ready(self, pid: int):
+        if self.ddp.delay_allreduce:
+            return
+        self.raw.mark_ready(pid, torch.cuda.current_stream().cuda_stream)
+
+    def finalize(self):
+        self.raw.finalize(torch.cuda.current_stream().cuda_stream)
 
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
-                 bucket_cap_mb: float = 32.0, first_bucket_mb: float = 1.0,
+                 bucket_cap_mb: float = 64.0, first_bucket_mb: float = 4.0,
                  delay_allreduce: bool = False, broadcast_buffers: bool = True,
-                 comm: str = "auto", chunk_mb: float = 64.0, verify_shapes: bool = True):
+                 comm: str = "auto", chunk_mb: float = 128.0, verify_shapes: bool = True):
         super().__init__()
         self.module = module
         self.delay_allreduce = delay_allreduce
@@ -117,23 +223,25 @@ class DistributedDataParallel(nn.Module):
         else:
             self.comm = None
         self.world_size = self.comm.world_size if self.comm is not None else 1
-        self.comm_stream = torch.cuda.Stream(self.device, priority=-1) if self.on_gpu else None
+        self.native = self.comm is not None and not isinstance(self.comm, TorchComm)
+        self.comm_stream = torch.cuda.Stream(self.device, priority=-1) \
+            if self.on_gpu and not self.native else None
 
         if self.world_size > 1:
             if verify_shapes:
                 self._verify_shapes()
             self._sync_module_states()
         self._buffer_arena()
-        self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes,
-                               single_bucket=delay_allreduce)
-        self._ready_order: List[int] = []
-        self._rebuilt = delay_allreduce or self.world_size == 1
         self._callback_queued = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
+        self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes,
+                               single_bucket=delay_allreduce, on_ready=self._on_sink_ready)
+        self.reducer = _NativeReducer(self, self.arena) if (self.native and self.world_size > 1) \
+            else _PyReducer(self, self.arena)
+        self.reducer.prepare()
         for p in self.params:
-            p.register_post_accumulate_grad_hook(self._make_hook(p))
-        self.comm_bytes_per_step = sum(b.flat.numel() * b.flat.element_size()
-                                       for b in self.arena.buckets)
+            p.register_post_accumulate_grad_hook(self._autograd_hook)
+        self.comm_bytes_per_step = sum(b.flat.numel() * b.flat.element_size() for b in self.arena.buckets)
 
     # ------------------------------------------------------------------ init-time sync
     def _verify_shapes(self) -> None:
@@ -146,14 +254,12 @@ class DistributedDataParallel(nn.Module):
 
     def _sync_module_states(self) -> None:
         """Rank 0's parameters and buffers become everyone's (C-c), coalesced per dtype."""
-        tensors = [p.data for p in self.module.parameters()] + \
-                  [b.data for b in self.module.buffers()]
+        tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
         by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
         for t in tensors:
             by_dtype.setdefault(t.dtype, []).append(t)
         for dtype, group in by_dtype.items():
-            flat = torch.cat([t.reshape(-1) if t.is_contiguous() else
-                              self._dense_flat(t) for t in group])
+            flat = torch.cat([self._dense_flat(t) for t in group])
             self.comm.broadcast(flat, 0)
             off = 0
             for t in group:
@@ -163,7 +269,7 @@ class DistributedDataParallel(nn.Module):
 
     @staticmethod
     def _dense_flat(t: torch.Tensor) -> torch.Tensor:
-        if t.dim() == 4:
+        if t.dim() == 4 and not t.is_contiguous():
             return t.permute(0, 2, 3, 1).reshape(-1)        # KRSC memory order
         return t.contiguous().reshape(-1)
 
@@ -176,8 +282,8 @@ class DistributedDataParallel(nn.Module):
             t.copy_(flat.view(t.shape))
 
     def _buffer_arena(self) -> None:
-        """Re-homes all float buffers (BN running stats) and all integer buffers
-        into two flat tensors so the per-forward broadcast is two collectives."""
+        """Re-homes all buffers (BN running stats, counters) into one flat tensor per dtype so the
+        per-forward broadcast is two collectives."""
         self._buf_flat: List[torch.Tensor] = []
         groups: Dict[torch.dtype, list] = {}
         for mod in self.module.modules():
@@ -202,8 +308,6 @@ class DistributedDataParallel(nn.Module):
                 and self.require_backward_grad_sync:
             for flat in self._buf_flat:
                 self.comm.broadcast(flat, 0)
-        if not self._rebuilt and len(self._ready_order) == len(self.params):
-            self._rebuild_buckets()
         return self.module(*inputs, **kwargs)
 
     @contextlib.contextmanager
@@ -214,91 +318,56 @@ class DistributedDataParallel(nn.Module):
         finally:
             self.require_backward_grad_sync = old
 
-    # ------------------------------------------------------------------ reducer
-    def _rebuild_buckets(self) -> None:
-        order = list(self._ready_order)
-        old = self.arena
-        self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes, order=order)
-        # carry over nothing: grads were consumed by the optimizer step already
-        del old
-        self._rebuilt = True
-        for opt in getattr(self, "_optimizers", []):
-            opt.register_flat_grads(self.arena.flat_buffers())
-
+    # ------------------------------------------------------------------ reducer plumbing
     def bind_optimizer(self, optimizer) -> None:
-        """Lets ``FusedSGD.zero_grad`` memset the flat buckets."""
-        self._optimizers = getattr(self, "_optimizers", []) + [optimizer]
-        if hasattr(optimizer, "register_flat_grads"):
-            optimizer.register_flat_grads(self.arena.flat_buffers())
+        """Lets the fused optimizer start each step on the arena (no per-parameter zeroing)."""
+        if hasattr(optimizer, "register_arena"):
+            optimizer.register_arena(self.arena)
 
-    def _make_hook(self, p: nn.Parameter):
-        def hook(param):
-            self._on_grad_ready(param)
-        return hook
-
-    def _on_grad_ready(self, p: nn.Parameter) -> None:
-        pid = self._index[id(p)]
-        bi = self.arena.bucket_of[pid]
-        b = self.arena.buckets[bi]
-        slot = b.spec.param_ids.index(pid)
-        view = b.views[slot]
-        if p.grad is not view:
-            # someone set grads to None (torch's default zero_grad): adopt the fresh grad
-            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
-        if not self.require_backward_grad_sync:
-            return
-        if not self._rebuilt:
-            self._ready_order.append(pid)
+    def _queue_callback(self) -> None:
         if not self._callback_queued:
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize_backward)
-        b.pending -= 1
-        if b.pending == 0 and not self.delay_allreduce:
-            self._launch(b)
 
-    def _launch(self, b: _Bucket) -> None:
-        b.launched = True
-        if self.world_size == 1:
+    def _on_sink_ready(self, sink) -> None:
+        """A backward kernel wrote ``sink.param``'s gradient into its bucket view."""
+        if not self.require_backward_grad_sync:
             return
-        nbytes = b.flat.numel() * b.flat.element_size()
-        pieces = [b.flat]
-        if nbytes > self.chunk_bytes:
-            pieces = [b.flat[s:e] for s, e in
-                      chunk_ranges(b.flat.numel(), b.flat.element_size(), self.chunk_bytes)]
-        if self.on_gpu:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ready)
-                for piece in pieces:
-                    b.work.append(self.comm.all_reduce_mean(piece, async_op=True))
-        else:
-            for piece in pieces:
-                b.work.append(self.comm.all_reduce_mean(piece, async_op=True))
+        self._queue_callback()
+        self.reducer.mark_ready(sink.index)
+
+    def _autograd_hook(self, param) -> None:
+        """Gradient arrived through autograd's AccumulateGrad (CPU reference ops, foreign modules)."""
+        sink = param._dpa_sink
+        if sink.written and param.grad is sink.view:
+            return                                  # already delivered by a kernel this step
+        if param.grad is not sink.view:
+            if param.grad is not None:
+                if sink.written:                    # earlier micro-batch of this step already in the view
+                    sink.view.add_(param.grad)
+                else:
+                    sink.view.copy_(param.grad)
+            param.grad = sink.view
+        sink.zeroed = False
+        sink.written = True
+        self._on_sink_ready(sink)
 
     def _finalize_backward(self) -> None:
         self._callback_queued = False
-        for b in self.arena.buckets:
-            if not b.launched:                 # delay_allreduce, or parameters unused this step
-                self._launch(b)
-        for b in self.arena.buckets:
-            for w in b.work:
-                w.wait()                        # GPU: stream-level wait; gloo: host wait
-            b.work = []
-            b.pending = len(b.params)
-            b.launched = False
-        if self.on_gpu and self.world_size > 1:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-        if not self._rebuilt and len(self._ready_order) != len(self.params):
-            self._ready_order = []             # partial graph: try again next iteration
+        self.arena.finish_step()
+        self.reducer.finalize()
+        self.reducer.prepare()
 
     # ------------------------------------------------------------------ conveniences
     def zero_grad(self, set_to_none: bool = False) -> None:
-        self.arena.zero()
+        if self.on_gpu:
+            self.arena.begin_step()
+            for p in self.params:
+                p.grad = None
+        else:
+            self.arena.zero()
+            self.arena.attach()
 
     def bucket_summary(self) -> List[dict]:
-        return [{"bucket": i, "params": len(b.params),
-                 "mbytes": b.flat.numel() * b.flat.element_size() / MiB}
+        return [{"bucket": i, "params": len(b.params), "mbytes": b.flat.numel() * b.flat.element_size() / MiB}
                 for i, b in enumerate(self.arena.buckets)]

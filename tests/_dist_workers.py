@@ -1,0 +1,89 @@
+"""Worker functions for multi-process (gloo, CPU) tests; must be importable by spawned children."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    from distributed_pytorch_amd import launch
+
+    launch.init_process_group("gloo", "tcp://127.0.0.1:%d" % port, world, rank, timeout_s=60, use_gpu=False)
+
+
+def _model(num_classes=10):
+    from distributed_pytorch_amd import models
+
+    torch.manual_seed(1234)
+    return models.create_model("resnet18", num_classes=num_classes)
+
+
+def ddp_grads(local_rank, world, port, out_dir, delay):
+    """Each rank: its shard of a fixed global batch -> save averaged grads + params after one step."""
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.ops import functional as F
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+
+    _init(local_rank, world, port)
+    model = _model()
+    if local_rank != 0:                     # DDP must broadcast rank 0's weights
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.5)
+    ddp = DistributedDataParallel(model, bucket_cap_mb=8.0, first_bucket_mb=0.5, delay_allreduce=delay)
+    opt = FusedSGD(ddp.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(8, 3, 32, 32, generator=g)
+    t = torch.randint(0, 10, (8,), generator=g)
+    per = 8 // world
+    xs, ts = x[local_rank * per:(local_rank + 1) * per], t[local_rank * per:(local_rank + 1) * per]
+    for m in model.modules():               # BN batch stats differ between sharded and full batch:
+        if hasattr(m, "running_mean"):      # freeze them so DDP == single-process on the full batch
+            m.eval()
+    loss = F.cross_entropy(ddp(xs), ts)
+    opt.zero_grad()
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in ddp.named_parameters()}
+    opt.step()
+    torch.save({"grads": grads, "params": {n: p.detach().clone() for n, p in ddp.named_parameters()},
+                "buckets": ddp.bucket_summary(), "keys": list(ddp.state_dict().keys())[:3]},
+               os.path.join(out_dir, "rank%d.pt" % local_rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def syncbn_stats(local_rank, world, port, out_dir):
+    from distributed_pytorch_amd.nn.modules import BatchNorm2d
+    from distributed_pytorch_amd.parallel import convert_syncbn_model
+
+    _init(local_rank, world, port)
+    torch.manual_seed(7)
+    x = torch.randn(8, 5, 5, 16)
+    bn = convert_syncbn_model(torch.nn.Sequential(BatchNorm2d(16)))[0]
+    per = 8 // world
+    xs = x[local_rank * per:(local_rank + 1) * per].clone().requires_grad_(True)
+    y = bn(xs)
+    (y * torch.arange(16.0)).sum().backward()
+    torch.save({"y": y.detach(), "dx": xs.grad, "rm": bn.running_mean.clone(), "rv": bn.running_var.clone(),
+                "dw": bn.weight.grad.clone()}, os.path.join(out_dir, "rank%d.pt" % local_rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def crash_one(local_rank, world, port):
+    """Rank 1 dies hard mid-run; the others would block in a collective forever."""
+    from distributed_pytorch_amd import launch
+
+    _init(local_rank, world, port)
+    t = torch.ones(4)
+    dist.all_reduce(t)
+    launch.maybe_fault_inject("1:0", local_rank, 0)
+    dist.all_reduce(t)          # never completes on the survivors without the supervisor
+    import time
+
+    time.sleep(120)

@@ -1,0 +1,178 @@
+"""Checkpoint dict compatibility, FusedSGD == torch.optim.SGD, loss-scaler state machine."""
+import os
+
+import pytest
+import torch
+
+from distributed_pytorch_amd import amp, checkpoint as ckpt, models
+from distributed_pytorch_amd.optim import FusedSGD
+
+
+def _tiny():
+    torch.manual_seed(0)
+    return models.create_model("resnet18", num_classes=10)
+
+
+def test_param_counts_and_torchvision_key_names():
+    want = {"resnet18": 11689512, "resnet50": 25557032, "alexnet": 61100840, "vgg16": 138357544}
+    for arch, n in want.items():
+        m = models.create_model(arch)
+        assert sum(p.numel() for p in m.parameters()) == n, arch
+    sd = models.create_model("resnet50").state_dict()
+    for k in ("conv1.weight", "bn1.running_mean", "bn1.num_batches_tracked", "layer1.0.conv1.weight",
+              "layer1.0.downsample.0.weight", "layer1.0.downsample.1.running_var", "layer4.2.bn3.bias", "fc.weight"):
+        assert k in sd, k
+    assert len(list(models.create_model("resnet50").parameters())) == 161
+    assert sd["conv1.weight"].shape == (64, 3, 7, 7)
+    va = models.create_model("vgg16").state_dict()
+    assert va["features.0.weight"].shape == (64, 3, 3, 3) and va["classifier.0.weight"].shape == (4096, 25088)
+    al = models.create_model("alexnet").state_dict()
+    assert al["features.0.weight"].shape == (64, 3, 11, 11) and al["classifier.1.weight"].shape == (4096, 9216)
+
+
+def test_checkpoint_roundtrip_reference_dict(tmp_path):
+    m = _tiny()
+    opt = FusedSGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    x = torch.randn(2, 3, 32, 32)
+    m(x).sum().backward()
+    opt.step()
+    state = ckpt.build_state(4, "resnet18", m, opt, torch.tensor(12.5), distributed=True)
+    assert set(state) == {"epoch", "arch", "state_dict", "best_acc1", "optimizer"} and state["epoch"] == 5
+    assert all(k.startswith("module.") for k in state["state_dict"])
+    assert all(v.dtype == torch.float32 for v in state["state_dict"].values() if v.is_floating_point())
+    assert state["state_dict"]["module.conv1.weight"].is_contiguous()         # plain OIHW in the file
+    path = ckpt.save_checkpoint(state, True, out_dir=str(tmp_path))
+    assert os.path.isfile(path) and os.path.isfile(tmp_path / ckpt.BEST_NAME)
+    m2 = _tiny()
+    for p in m2.parameters():
+        p.data.add_(1.0)
+    opt2 = FusedSGD(m2.parameters(), lr=0.5, momentum=0.9)
+    start, best = ckpt.resume(path, m2, opt2, verbose=False)
+    assert start == 5 and best == 12.5
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert opt2.param_groups[0]["lr"] == 0.1
+    b1 = opt.state_dict()["state"][0]["momentum_buffer"]
+    assert torch.equal(opt2.state_dict()["state"][0]["momentum_buffer"], b1)
+
+
+def test_loads_checkpoint_written_by_stock_torch(tmp_path):
+    """A file produced the reference's way: torch.optim.SGD state, 'features.module.' / 'module.' prefixes,
+    fp16 weights, best_prec1 key."""
+    m = _tiny()
+    ref_opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    m(torch.randn(2, 3, 32, 32)).sum().backward()
+    ref_opt.step()
+    sd = {"module." + k: (v.half() if v.is_floating_point() else v) for k, v in m.state_dict().items()}
+    torch.save({"epoch": 7, "arch": "resnet18", "state_dict": sd, "best_prec1": 33.0,
+                "optimizer": ref_opt.state_dict()}, tmp_path / "c.pth.tar")
+    m2 = _tiny()
+    opt2 = FusedSGD(m2.parameters(), lr=0.1, momentum=0.9)
+    start, best = ckpt.resume(str(tmp_path / "c.pth.tar"), m2, opt2, verbose=False)
+    assert (start, best) == (7, 33.0) and opt2.param_groups[0]["lr"] == 0.05
+    assert torch.allclose(m2.conv1.weight, m.conv1.weight.half().float())
+    assert m2.conv1.weight.dtype == torch.float32
+    # and the reverse: torch's SGD loads OUR optimizer state
+    torch.optim.SGD(m.parameters(), lr=1.0, momentum=0.9).load_state_dict(opt2.state_dict())
+    assert ckpt.strip_prefixes({"features.module.0.weight": 1, "module.fc.bias": 2}) == \
+        {"features.0.weight": 1, "fc.bias": 2}
+
+
+def test_corrupt_checkpoint_is_a_clean_error(tmp_path):
+    p = tmp_path / "bad.pth.tar"
+    p.write_bytes(b"PK\x03\x04 truncated")
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.load_checkpoint(str(p))
+    torch.save({"not": "a checkpoint"}, tmp_path / "other.pth")
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.load_checkpoint(str(tmp_path / "other.pth"))
+    assert ckpt.resume(str(tmp_path / "missing.pth"), _tiny(), verbose=False) is None
+
+
+@pytest.mark.parametrize("nesterov,wd", [(False, 1e-4), (True, 0.0)])
+def test_fused_sgd_cpu_matches_torch(nesterov, wd):
+    torch.manual_seed(1)
+    ps = [torch.randn(5, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a = FusedSGD(ps, lr=0.1, momentum=0.9, weight_decay=wd, nesterov=nesterov)
+    b = torch.optim.SGD(qs, lr=0.1, momentum=0.9, weight_decay=wd, nesterov=nesterov)
+    assert a.state_dict()["state"] == {} and a.state_dict()["param_groups"][0]["params"] == [0, 1]
+    for _ in range(5):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, atol=1e-6)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    assert torch.allclose(sa["state"][0]["momentum_buffer"], sb["state"][0]["momentum_buffer"], atol=1e-6)
+    assert {k for k in sb["param_groups"][0]} <= {k for k in sa["param_groups"][0]}
+
+
+def test_loss_scaler_state_machine_cpu():
+    s = amp.LossScaler(torch.device("cpu"), init_scale=2.0 ** 16, dynamic=True, growth_interval=3)
+    p = torch.ones(4, requires_grad=True)
+    opt = FusedSGD([p], lr=1.0)
+    p.grad = torch.tensor([1.0, float("nan"), 1.0, 1.0])
+    s.check_overflow([p.grad])
+    opt.arm_scaler(s)
+    opt.step()
+    assert torch.equal(p.detach(), torch.ones(4)) and s.loss_scale() == 2.0 ** 15      # skipped + halved
+    for i in range(3):
+        p.grad = torch.full((4,), 2.0 ** 15)
+        s.check_overflow([p.grad])
+        opt.arm_scaler(s)
+        opt.step()
+        assert torch.allclose(p.detach(), torch.full((4,), -float(i)))                  # unscaled grad == 1
+    assert s.loss_scale() == 2.0 ** 16                                                   # grew after 3 clean steps
+    sd = s.state_dict()
+    s2 = amp.LossScaler(torch.device("cpu"))
+    s2.load_state_dict(sd)
+    assert s2.loss_scale() == s.loss_scale()
+
+
+def test_amp_initialize_levels_and_scale_loss_cpu():
+    m = _tiny()
+    opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9)
+    m, opt = amp.initialize(m, opt, opt_level="O1", dtype="bf16")
+    assert amp.compute_dtype() == torch.bfloat16 and m.conv1.weight.dtype == torch.float32
+    out = m(torch.randn(2, 3, 32, 32))
+    assert out.dtype == torch.float32              # logits leave the network in fp32
+    loss = out.float().logsumexp(1).mean()
+    with amp.scale_loss(loss, opt) as scaled:
+        scaled.backward()
+    assert m.conv1.weight.grad is not None and m.conv1.weight.grad.dtype == torch.float32
+    opt.step()
+    m2 = _tiny()
+    opt2 = FusedSGD(m2.parameters(), lr=0.01)
+    amp.initialize(m2, opt2, opt_level="O2", dtype="fp16", loss_scale="dynamic")
+    assert amp.state().scaler.dynamic and amp.state().scaler.loss_scale() == 2.0 ** 16
+    amp.initialize(m2, opt2, opt_level="O0")
+    assert amp.compute_dtype(torch.float32) == torch.float32
+    with pytest.raises(ValueError):
+        amp.initialize(m2, opt2, opt_level="O9")
+    amp.state().reset()
+
+
+def test_tfevents_writer_records_are_well_formed(tmp_path):
+    import struct
+
+    from distributed_pytorch_amd.utils.tb import SummaryWriter, _masked_crc
+
+    w = SummaryWriter(log_dir=str(tmp_path / "run"), comment="_x")
+    w.add_scalar("Loss/train", 1.5, 3)
+    w.close()
+    files = [f for f in os.listdir(w.log_dir) if "tfevents" in f]
+    assert len(files) == 1
+    raw = open(os.path.join(w.log_dir, files[0]), "rb").read()
+    off, n = 0, 0
+    while off < len(raw):
+        (length,) = struct.unpack("<Q", raw[off:off + 8])
+        assert struct.unpack("<I", raw[off + 8:off + 12])[0] == _masked_crc(raw[off:off + 8])
+        payload = raw[off + 12:off + 12 + length]
+        assert struct.unpack("<I", raw[off + 12 + length:off + 16 + length])[0] == _masked_crc(payload)
+        off += 16 + length
+        n += 1
+    assert n == 2 and b"Loss/train" in raw           # version record + one scalar

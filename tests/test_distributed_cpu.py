@@ -1,0 +1,135 @@
+"""Multi-process data parallelism on the CPU (gloo, world_size 2): the plumbing configuration of
+BASELINE.json #1.  Covers the bucket planner, the reducer state machine, DDP == single process on the
+concatenated batch, SyncBN statistics, the launcher's failure propagation and the trainers end to end."""
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+import _dist_workers as W
+from distributed_pytorch_amd import launch
+from distributed_pytorch_amd.parallel.bucketing import MiB, chunk_ranges, plan_buckets_py
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bucket_planner_caps_order_and_alignment():
+    numels = [1000, 300000, 50, 2000000, 700]
+    specs = plan_buckets_py(numels, [4] * 5, [0] * 5, [4, 3, 2, 1, 0], cap_bytes=2 * MiB, first_cap_bytes=1024)
+    assert [s.param_ids for s in specs] == [[4], [3], [2, 1, 0]]          # small first bucket, oversize alone
+    for s in specs:
+        assert all(off * 4 % 256 == 0 for off in s.offsets) and s.total >= sum(s.numels)
+    mixed = plan_buckets_py([10, 10, 10], [4, 2, 4], [0, 1, 0], [2, 1, 0], 1 << 30, 1 << 30)
+    assert sorted(tuple(s.param_ids) for s in mixed) == [(1,), (2, 0)]    # buckets are dtype-homogeneous
+    assert chunk_ranges(10, 4, 16) == [(0, 4), (4, 8), (8, 10)]
+
+
+@pytest.mark.parametrize("delay", [False, True])
+def test_ddp_matches_single_process_on_full_batch(tmp_path, delay):
+    world = 2
+    launch.spawn(W.ddp_grads, world, (world, _port(), str(tmp_path), delay))
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    for n in r0["grads"]:
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n             # identical after all-reduce
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
+    assert r0["keys"][0].startswith("module.")
+    if delay:
+        assert len(r0["buckets"]) == 1
+    else:
+        assert len(r0["buckets"]) > 1
+    # oracle: one process, whole batch (mean loss over 8 == mean of the two shard means)
+    from distributed_pytorch_amd.ops import functional as F
+
+    model = W._model()
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(8, 3, 32, 32, generator=g)
+    t = torch.randint(0, 10, (8,), generator=g)
+    for m in model.modules():
+        if hasattr(m, "running_mean"):
+            m.eval()
+    F.cross_entropy(model(x), t).backward()
+    for n, p in model.named_parameters():
+        got = r0["grads"]["module." + n]
+        assert torch.allclose(got, p.grad, rtol=1e-3, atol=1e-5), (n, (got - p.grad).abs().max())
+
+
+def test_syncbn_equals_batchnorm_over_the_global_batch(tmp_path):
+    world = 2
+    launch.spawn(W.syncbn_stats, world, (world, _port(), str(tmp_path)))
+    rs = [torch.load(tmp_path / ("rank%d.pt" % r), weights_only=True) for r in range(world)]
+    torch.manual_seed(7)
+    x = torch.randn(8, 5, 5, 16).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(16)
+    y = bn(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    (y * torch.arange(16.0)).sum().backward()
+    assert torch.allclose(torch.cat([r["y"] for r in rs]), y, atol=1e-5)
+    assert torch.allclose(torch.cat([r["dx"] for r in rs]), x.grad, atol=1e-5)
+    assert torch.allclose(rs[0]["rm"], bn.running_mean, atol=1e-6) and torch.allclose(rs[1]["rv"], bn.running_var, atol=1e-5)
+    assert torch.allclose(rs[0]["dw"] + rs[1]["dw"], bn.weight.grad, atol=1e-4)     # local sums; DDP averages
+
+
+def test_rank_failure_tears_the_job_down_instead_of_hanging():
+    t0 = time.time()
+    with pytest.raises(launch.ProcessFailure) as e:
+        launch.spawn(W.crash_one, 2, (2, _port()))
+    assert e.value.exitcode == 17 and e.value.local_rank == 1
+    assert time.time() - t0 < 60
+
+
+def _run(script, *argv, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", script)] + list(argv)
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+
+
+def test_nd_trainer_cpu_trains_checkpoints_and_resumes(tmp_path):
+    common = ["--synthetic", "-a", "resnet18", "-b", "8", "-p", "2", "--cpu", "--synthetic-size", "32",
+              "--synthetic-val-size", "8", "--num-classes", "10", "--lr", "0.01", "--out-dir", str(tmp_path)]
+    r = _run("nd_imagenet.py", *common, "--epochs", "1", "--seed", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "using CPU, this will be slow" in r.stdout and "Epoch: [0][4/4]" in r.stdout and " * " in r.stdout
+    ck = torch.load(tmp_path / "checkpoint.pth.tar", weights_only=True)
+    assert set(ck) == {"epoch", "arch", "state_dict", "best_acc1", "optimizer"} and ck["epoch"] == 1
+    assert "conv1.weight" in ck["state_dict"]                                  # unwrapped: no module. prefix
+    r2 = _run("nd_imagenet.py", *common, "--epochs", "2", "--resume", str(tmp_path / "checkpoint.pth.tar"))
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "(epoch 1)" in r2.stdout and "Epoch: [1]" in r2.stdout and "Epoch: [0]" not in r2.stdout
+    r3 = _run("nd_imagenet.py", *common, "--evaluate")
+    assert r3.returncode == 0 and "Epoch:" not in r3.stdout and "Test:" in r3.stdout
+
+
+def test_ddp_trainer_two_gloo_ranks_and_desired_acc_stop(tmp_path):
+    r = _run("imagenet_ddp.py", "--synthetic", "-a", "resnet18", "-b", "16", "-p", "1", "--cpu", "--steps", "2",
+             "--synthetic-size", "64", "--synthetic-val-size", "16", "--num-classes", "10", "--epochs", "3",
+             "--dist-url", "tcp://127.0.0.1:%d" % _port(), "--dist-backend", "gloo", "--world-size", "1",
+             "--rank", "0", "--desired-acc", "0.0", "--out-dir", str(tmp_path), env={"DPA_NPROC_PER_NODE": "2"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("=> creating model 'resnet18'") == 2                # one process per "GPU"
+    assert "Epoch: [0][2/2]" in r.stdout
+    ck = torch.load(tmp_path / "checkpoint.pth.tar", weights_only=True)
+    assert "module.conv1.weight" in ck["state_dict"]                          # saved from the DDP wrapper
+
+
+def test_amp_trainer_env_rendezvous_single_rank(tmp_path):
+    r = _run("imagenet_ddp_apex.py", "--synthetic", "-a", "resnet18", "-b", "8", "-p", "1", "--cpu", "--steps", "2",
+             "--synthetic-size", "32", "--synthetic-val-size", "8", "--num-classes", "10", "--epochs", "1",
+             "--opt-level", "O1", "--out-dir", str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "opt_level = O1" in r.stdout and "Throughput" in r.stdout and "### Training Time:" in r.stdout
+    ck = torch.load(tmp_path / "checkpoint.pth.tar", weights_only=True)
+    assert "best_prec1" in ck and "best_acc1" in ck
+    assert any("tfevents" in f for f in os.listdir(tmp_path))
