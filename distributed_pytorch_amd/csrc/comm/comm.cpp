@@ -1,7 +1,7 @@
 // Native data-parallel communication runtime for one-process-per-GPU training on MI355X.
 //
 //  * Communicator: owns an RCCL communicator (ncclCommInitRank from a unique id that Python
-//    exchanges through the rendezvous store) and a dedicated high-priority HIP stream, so
+//    exchanges through the rendezvous store) and a dedicated HIP stream, so
 //    collectives run beside compute instead of in its queue.
 //  * BucketReducer: the DDP gradient reducer.  Gradients live as VIEWS inside a few large flat
 //    buckets (no flatten / unflatten copies).  When backward has produced every gradient of a
@@ -128,9 +128,17 @@ class Communicator {
       py::gil_scoped_release nogil;
       check_nccl(rccl().CommInitRank(&comm_, world, uid, rank), "ncclCommInitRank");
     }
-    int lo = 0, hi = 0;
-    CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CHECK_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+    // Normal priority on purpose.  A high-priority stream that event-waits on work of torch's default
+    // (null) stream DEADLOCKED on MI355X / ROCm 7.0 runtime with GPU_MAX_HW_QUEUES=4 (both streams stay
+    // busy forever, measured 2026-11: profiles/r1_notes.md); DPA_COMM_PRIORITY=1 opts back in.
+    const char* prio = getenv("DPA_COMM_PRIORITY");
+    if (prio && std::string(prio) == "1") {
+      int lo = 0, hi = 0;
+      CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CHECK_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+    } else {
+      CHECK_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    }
   }
   ~Communicator() {
     if (comm_) {

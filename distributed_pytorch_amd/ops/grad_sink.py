@@ -17,26 +17,41 @@ import torch
 
 
 class GradSink:
-    __slots__ = ("param", "view", "index", "on_ready", "written", "zeroed", "arena")
+    __slots__ = ("param", "view", "index", "on_ready", "stamp", "zeroed", "arena", "uses")
 
     def __init__(self, param, view: torch.Tensor, index: int, on_ready: Optional[Callable] = None,
                  arena=None):
         self.param, self.view, self.index, self.on_ready = param, view, index, on_ready
         self.arena = arena
-        self.written = False      # a gradient was delivered this iteration
+        self.stamp = -1           # arena epoch of the last delivery ("written this iteration")
         self.zeroed = True        # the view currently holds zeros (fresh / memset)
+        self.uses = 0             # forward uses whose backward has not delivered yet (shared weights)
+
+    @property
+    def written(self) -> bool:
+        return self.stamp == self.arena.epoch
+
+    @written.setter
+    def written(self, flag: bool) -> None:
+        self.stamp = self.arena.epoch if flag else -1
 
     def beta(self) -> float:
         """Accumulation factor for the next kernel writing into the view."""
         return 1.0 if self.written else 0.0
 
     def delivered(self) -> None:
+        """A kernel has just written (beta() = 0) or accumulated (1) this gradient into the view."""
+        p = self.param
+        g = p.grad
+        if g is not None and g is not self.view:
+            self.view.add_(g)     # a part that arrived through autograd earlier in this backward
         self.written = True
         self.zeroed = False
-        p = self.param
-        if p.grad is not self.view:
+        if g is not self.view:
             p.grad = self.view
-        if self.on_ready is not None:
+        self.uses -= 1
+        if self.on_ready is not None and self.uses <= 0:   # the LAST use completes the gradient
+            self.uses = 0
             self.on_ready(self)
 
 
@@ -47,3 +62,14 @@ def sink_of(param) -> Optional[GradSink]:
             or s.view.dtype != torch.float32:
         return None
     return s
+
+
+def note_use(*params) -> None:
+    """Forward-time bookkeeping: one more backward delivery is owed to each parameter's sink."""
+    if not torch.is_grad_enabled():
+        return
+    for p in params:
+        if p is not None:
+            s = getattr(p, "_dpa_sink", None)
+            if s is not None and p.requires_grad:
+                s.uses += 1

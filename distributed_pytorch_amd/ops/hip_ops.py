@@ -389,6 +389,7 @@ def _slice_channels(src: torch.Tensor, dst: torch.Tensor, keep: int) -> None:
 
 
 def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad):
+    grad_sink.note_use(weight, bias)
     return _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
                          bool(needs_input_grad))
 
@@ -555,6 +556,7 @@ class _BNEvalFn(torch.autograd.Function):
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps,
                relu, residual, stats, group):
     if training or running_mean is None:
+        grad_sink.note_use(weight, bias)
         return _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
                            running_var if training else None, num_batches_tracked if training else None,
                            float(momentum if momentum is not None else 0.1), float(eps), bool(relu), stats, group)
@@ -791,6 +793,7 @@ class _LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias, relu, w_lp, out_dtype):
+    grad_sink.note_use(weight, bias)
     return _LinearFn.apply(x, weight, bias, bool(relu), out_dtype)
 
 

@@ -119,6 +119,8 @@ class FusedSGD(Optimizer):
             self._step_hip(scaler)
         else:
             self._step_reference(scaler)
+        for arena in self._arenas():
+            arena.end_step()
         if scaler is not None:
             scaler.update()
         self._steps += 1

@@ -68,6 +68,7 @@ class GradArena:
     def __init__(self, params: List[nn.Parameter], cap_bytes: int = 1 << 62, first_cap_bytes: int = 1 << 62,
                  order: Optional[List[int]] = None, single_bucket: bool = False, on_ready=None):
         self.params = list(params)
+        self.epoch = 0
         n = len(self.params)
         order = list(range(n - 1, -1, -1)) if order is None else order
         dtypes = sorted({p.dtype for p in self.params}, key=str)
@@ -91,6 +92,9 @@ class GradArena:
             s = grad_sink.GradSink(p, self.view_of[pid], pid, on_ready, self)
             p._dpa_sink = s
             self.sinks.append(s)
+            if p.grad is not None:                  # keep a gradient that already exists
+                s.view.copy_(p.grad)
+                s.written, s.zeroed = True, False
         self.attach()
 
     def attach(self) -> None:
@@ -101,24 +105,43 @@ class GradArena:
         return [b.flat for b in self.buckets]
 
     def zero(self) -> None:
+        """Memset every bucket (CPU arenas: autograd accumulates in place into the views)."""
         for b in self.buckets:
             b.flat.zero_()
-        self.begin_step(zeroed=True)
-
-    def begin_step(self, zeroed: bool = False) -> None:
-        """New iteration: the first delivery into every sink overwrites (``zeroed`` buckets: adds)."""
+        self.begin_step()
         for s in self.sinks:
-            s.written = False
-            s.zeroed = zeroed
+            s.zeroed = True
 
-    def finish_step(self) -> None:
-        """Gradient slots nobody wrote this iteration (unused parameters) must read as zero."""
+    def begin_step(self) -> None:
+        """New iteration: the first delivery into every sink overwrites instead of accumulating."""
+        self.epoch += 1
+
+    def finish_backward(self) -> None:
+        """End of a backward pass: fold in gradients that did not come through a sink (autograd's
+        AccumulateGrad, user-assigned ``.grad``) and make never-touched slots read as zero."""
         for s in self.sinks:
-            if not s.written and not s.zeroed:
-                s.view.zero_()
+            g = s.param.grad
+            if g is s.view:
+                continue
+            if g is not None:
+                if s.written:
+                    s.view.add_(g)
+                else:
+                    s.view.copy_(g)
+                s.written = True
+                s.zeroed = False
+            elif not s.written and not s.zeroed:
+                s.view.zero_()              # parameter unused this iteration
                 s.zeroed = True
-            if s.param.grad is not s.view:
-                s.param.grad = s.view
+            s.param.grad = s.view
+
+    finish_step = finish_backward
+
+    def end_step(self) -> None:
+        """The optimizer consumed the gradients: later deliveries start a new iteration."""
+        self.epoch += 1
+        for s in self.sinks:
+            s.uses = 0
 
 
 class _PyReducer:
@@ -224,7 +247,7 @@ class DistributedDataParallel(nn.Module):
             self.comm = None
         self.world_size = self.comm.world_size if self.comm is not None else 1
         self.native = self.comm is not None and not isinstance(self.comm, TorchComm)
-        self.comm_stream = torch.cuda.Stream(self.device, priority=-1) \
+        self.comm_stream = torch.cuda.Stream(self.device) \
             if self.on_gpu and not self.native else None
 
         if self.world_size > 1:
@@ -236,7 +259,10 @@ class DistributedDataParallel(nn.Module):
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes,
                                single_bucket=delay_allreduce, on_ready=self._on_sink_ready)
-        self.reducer = _NativeReducer(self, self.arena) if (self.native and self.world_size > 1) \
+        import os as _os
+
+        force = _os.environ.get("DPA_FORCE_NATIVE_REDUCER", "0") == "1"     # world_size 1 test hook
+        self.reducer = _NativeReducer(self, self.arena) if (self.native and (self.world_size > 1 or force)) \
             else _PyReducer(self, self.arena)
         self.reducer.prepare()
         for p in self.params:
@@ -339,8 +365,6 @@ class DistributedDataParallel(nn.Module):
     def _autograd_hook(self, param) -> None:
         """Gradient arrived through autograd's AccumulateGrad (CPU reference ops, foreign modules)."""
         sink = param._dpa_sink
-        if sink.written and param.grad is sink.view:
-            return                                  # already delivered by a kernel this step
         if param.grad is not sink.view:
             if param.grad is not None:
                 if sink.written:                    # earlier micro-batch of this step already in the view

@@ -1,0 +1,90 @@
+"""GPU-side checks of the data-parallel runtime that fit a 1-GPU box: gradient arena / sinks, the native
+RCCL communicator and the C++ bucket reducer at world_size 1 (multi-rank logic is covered over gloo in
+test_distributed_cpu.py; RCCL refuses two ranks on one device)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(model, opt, x, t):
+    from distributed_pytorch_amd.ops import functional as F
+
+    loss, _ = F.loss_and_metrics(model(x), t)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return float(loss)
+
+
+def test_arena_sinks_match_plain_autograd_grads():
+    """Same model / batch: gradients delivered through sinks == gradients returned through autograd."""
+    import copy
+
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.ops import functional as F
+    from distributed_pytorch_amd.parallel import GradArena
+
+    amp.state().reset()
+    torch.manual_seed(0)
+    a = models.create_model("resnet18", num_classes=10).cuda().train()
+    b = copy.deepcopy(a)
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    t = torch.randint(0, 10, (8,), device="cuda")
+    F.cross_entropy(a(x), t).backward()
+    arena = GradArena(list(b.parameters()))
+    for _ in range(2):                       # second pass: views are overwritten, not accumulated
+        arena.begin_step()
+        for p in b.parameters():
+            p.grad = None
+        F.cross_entropy(b(x), t).backward()
+        arena.finish_step()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert q.grad is q._dpa_sink.view, n
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6), n
+    assert len(arena.buckets) == 1 and arena.buckets[0].flat.numel() >= sum(p.numel() for p in b.parameters())
+    # accumulation (two backward passes without begin_step) doubles the gradient
+    F.cross_entropy(b(x), t).backward()
+    assert torch.allclose(b.fc.weight.grad, 2 * a.fc.weight.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_native_comm_and_cpp_reducer_world1():
+    import torch.distributed as dist
+
+    from distributed_pytorch_amd import amp, backend, models
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+    from distributed_pytorch_amd.parallel.native_comm import NativeComm
+
+    amp.state().reset()
+    assert backend.require().rccl_version() > 20000
+    os.environ["DPA_FORCE_NATIVE_REDUCER"] = "1"
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29651", world_size=1, rank=0,
+                            device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(0)
+        model = models.create_model("resnet18", num_classes=10).cuda().train()
+        ddp = DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=8.0, first_bucket_mb=1.0)
+        assert isinstance(ddp.comm, NativeComm) and type(ddp.reducer).__name__ == "_NativeReducer"
+        assert ddp.reducer.raw.num_buckets == len(ddp.arena.buckets) > 1
+        opt = FusedSGD(ddp.parameters(), lr=0.05, momentum=0.9)
+        x = torch.randint(0, 256, (16, 64, 64, 3), dtype=torch.uint8, device="cuda")
+        t = torch.randint(0, 10, (16,), device="cuda")
+        losses = [_step(ddp, opt, x, t) for _ in range(8)]
+        torch.cuda.synchronize()
+        assert losses[-1] < losses[0], losses
+        assert ddp.comm.raw.async_error() == ""
+        # collectives of the communicator itself
+        v = torch.arange(8, dtype=torch.float32, device="cuda")
+        ddp.comm.all_reduce_sum(v).wait()
+        ddp.comm.broadcast(v, 0)
+        out = torch.empty(8, dtype=torch.float32, device="cuda")
+        ddp.comm.all_gather(out, v)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), torch.arange(8, dtype=torch.float32))
+        assert list(ddp.state_dict().keys())[0].startswith("module.")
+    finally:
+        os.environ.pop("DPA_FORCE_NATIVE_REDUCER", None)
+        dist.destroy_process_group()
