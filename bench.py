@@ -78,7 +78,8 @@ def main():
         from distributed_pytorch_amd.parallel import DistributedDataParallel
 
         kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
-        model = DistributedDataParallel(model, device_ids=[local_rank], **kw)
+        # Apex DDP (the reference's AMP script) does not re-broadcast BN buffers every forward
+        model = DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False, **kw)
     model.train()
 
     total = args.steps + args.warmup + 2

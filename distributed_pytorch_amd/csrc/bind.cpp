@@ -24,13 +24,15 @@ PYBIND11_MODULE(_C, m) {
   m.attr("IGEMM_SCATTER") = (int)kIgemmScatter;
 
   m.def("igemm",
-        [](uintptr_t A, uintptr_t B, uintptr_t C, uintptr_t bias, uintptr_t stats, uintptr_t taps, int M, int N,
+        [](uintptr_t A, uintptr_t B, uintptr_t C, uintptr_t R, uintptr_t bias, uintptr_t stats, uintptr_t taps, int M,
+           int N,
            int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
            int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream) {
           IgemmParams p;
           p.A = ptr<const void>(A);
           p.B = ptr<const void>(B);
           p.C = ptr<void>(C);
+          p.R = ptr<const void>(R);
           p.bias = ptr<const float>(bias);
           p.stats = ptr<float>(stats);
           p.taps = ptr<const int>(taps);
@@ -97,19 +99,33 @@ PYBIND11_MODULE(_C, m) {
                     ptr<const float>(shift), relu, st(s));
   });
   m.def("bn_bwd_reduce", [](uintptr_t dy, uintptr_t x, uintptr_t y, long M, int C, int dtype, uintptr_t mean,
-                            uintptr_t invstd, int relu, uintptr_t partial, int nblk, uintptr_t s) {
+                            uintptr_t invstd, int relu, uintptr_t scale, uintptr_t shift, uintptr_t partial, int nblk,
+                            uintptr_t s) {
     bn_bwd_reduce_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const void>(y), M, C, dtype,
-                         ptr<const float>(mean), ptr<const float>(invstd), relu, ptr<float>(partial), nblk, st(s));
+                         ptr<const float>(mean), ptr<const float>(invstd), relu, ptr<const float>(scale),
+                         ptr<const float>(shift), ptr<float>(partial), nblk, st(s));
   });
   m.def("bn_bwd_finalize", [](uintptr_t partial, int nparts, int C, uintptr_t dgamma, uintptr_t dbeta, uintptr_t s) {
     bn_bwd_finalize_launch(ptr<const float>(partial), nparts, C, ptr<float>(dgamma), ptr<float>(dbeta), st(s));
   });
+  m.def("bn_bwd_finalize_fused", [](uintptr_t partial, int nparts, int C, uintptr_t dgamma, uintptr_t dbeta,
+                                     uintptr_t mean, uintptr_t invstd, uintptr_t gamma, double count, uintptr_t coef,
+                                     uintptr_t scale, uintptr_t shift, uintptr_t s) {
+    bn_bwd_finalize_fused_launch(ptr<const float>(partial), nparts, C, ptr<float>(dgamma), ptr<float>(dbeta),
+                                 ptr<const float>(mean), ptr<const float>(invstd), ptr<const float>(gamma), count,
+                                 ptr<float>(coef), ptr<const float>(scale), ptr<const float>(shift), st(s));
+  });
+  m.def("bn_bwd_coeffs", [](uintptr_t dgamma, uintptr_t dbeta, uintptr_t mean, uintptr_t invstd, uintptr_t gamma,
+                            double count, uintptr_t count_dev, int C, uintptr_t coef, uintptr_t scale, uintptr_t shift,
+                            uintptr_t s) {
+    bn_bwd_coeffs_launch(ptr<const float>(dgamma), ptr<const float>(dbeta), ptr<const float>(mean),
+                         ptr<const float>(invstd), ptr<const float>(gamma), count, ptr<const float>(count_dev), C,
+                         ptr<float>(coef), ptr<const float>(scale), ptr<const float>(shift), st(s));
+  });
   m.def("bn_bwd_apply", [](uintptr_t dy, uintptr_t x, uintptr_t y, uintptr_t dx, uintptr_t dres, long M, int C,
-                           int dtype, uintptr_t mean, uintptr_t invstd, uintptr_t gamma, uintptr_t dgamma,
-                           uintptr_t dbeta, double count, uintptr_t count_dev, uintptr_t coef, int relu, uintptr_t s) {
+                           int dtype, uintptr_t coef, int relu, uintptr_t s) {
     bn_bwd_apply_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const void>(y), ptr<void>(dx), ptr<void>(dres), M,
-                        C, dtype, ptr<const float>(mean), ptr<const float>(invstd), ptr<const float>(gamma),
-                        ptr<const float>(dgamma), ptr<const float>(dbeta), count, ptr<const float>(count_dev), ptr<float>(coef), relu, st(s));
+                        C, dtype, ptr<const float>(coef), relu, st(s));
   });
 
   // ---- pooling

@@ -29,6 +29,8 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
                                                                 const T* __restrict__ y, long M, int C,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
                                                                 float* __restrict__ partial, long rows_per_block) {
   constexpr int VEC = 16 / (int)sizeof(T);
   __shared__ float red[2][kBnThreads * VEC];
@@ -41,18 +43,25 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   const bool active = rl < rp;
   const int c0 = (cc0 + col) * VEC;
 
-  float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+  // relu: 0 none, 1 mask = (y > 0) read from the saved output, 2 mask = (scale*x + shift > 0) recomputed
+  // from x (no residual): the output tensor is not read at all
+  float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     s1[j] = s2[j] = 0.f;
     mu[j] = 0.f;
     is[j] = 1.f;
+    sc[j] = sh[j] = 0.f;
   }
   if (MODE == 1 && active) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = mean[c0 + j];
       is[j] = invstd[c0 + j];
+      if (relu == 2) {
+        sc[j] = scale[c0 + j];
+        sh[j] = shift[c0 + j];
+      }
     }
   }
   const long r_begin = (long)blockIdx.x * rows_per_block;
@@ -72,12 +81,14 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       } else {
         Vec16<T> vx, vy;
         vx.load(x + off);
-        if (relu) vy.load(y + off);
+        if (relu == 1) vy.load(y + off);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float d = va.get(j);
-          if (relu && !(vy.get(j) > 0.f)) d = 0.f;
-          const float xh = (vx.get(j) - mu[j]) * is[j];
+          const float xv = vx.get(j);
+          if (relu == 1 && !(vy.get(j) > 0.f)) d = 0.f;
+          if (relu == 2 && !(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
+          const float xh = (xv - mu[j]) * is[j];
           s1[j] += d;
           s2[j] += d * xh;
         }
@@ -229,9 +240,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                      const float* __restrict__ gamma, float inv_count,
-                                     const float* __restrict__ count_dev, int C, float* __restrict__ coef) {
+                                     const float* __restrict__ count_dev, int C, float* __restrict__ coef,
+                                     const float* __restrict__ scale, const float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  coef[3 * C + c] = scale ? scale[c] : 0.f;
+  coef[4 * C + c] = shift ? shift[c] : 0.f;
   if (count_dev != nullptr) inv_count = 1.f / count_dev[0];
   const float is = invstd[c], g = gamma ? gamma[c] : 1.f;
   const float A = g * is;
@@ -239,6 +253,42 @@ __global__ void bn_bwd_coeffs_kernel(const float* __restrict__ dgamma, const flo
   coef[c] = A;
   coef[C + c] = B;
   coef[2 * C + c] = -A * dbeta[c] * inv_count - B * mean[c];
+}
+
+// One launch: fold [nparts][2][C] partials (4 part lanes x 64 channels per workgroup, fixed order),
+// write dgamma / dbeta and -- when the element count is known here (no SyncBN all-reduce in
+// between) -- the apply-pass coefficients.  Replaces fold + sum + coeffs (3 tiny launches).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_fused_kernel(
+    const float* __restrict__ partial, int nparts, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    float inv_count, float* __restrict__ coef, const float* __restrict__ scale, const float* __restrict__ shift) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int k = pl; k < nparts; k += 4) {
+      s1 += partial[((size_t)k * 2 + 0) * C + c];
+      s2 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+  red[0][pl][cl] = s1;
+  red[1][pl][cl] = s2;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  const float db = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  const float dg = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  dbeta[c] = db;
+  dgamma[c] = dg;
+  if (coef != nullptr) {
+    const float is = invstd[c], g = gamma ? gamma[c] : 1.f;
+    const float A = g * is;
+    const float B = -A * is * dg * inv_count;
+    coef[c] = A;
+    coef[C + c] = B;
+    coef[2 * C + c] = -A * db * inv_count - B * mean[c];
+    coef[3 * C + c] = scale ? scale[c] : 0.f;
+    coef[4 * C + c] = shift ? shift[c] : 0.f;
+  }
 }
 
 template <typename T>
@@ -250,27 +300,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const long stride = (long)gridDim.x * blockDim.x;
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  float ca[VEC], cb[VEC], ck[VEC];
+  float ca[VEC], cb[VEC], ck[VEC], sc[VEC], sh[VEC];
   int c0 = (int)(i % cc) * VEC;
   load_coef<VEC>(coef, c0, ca);
   load_coef<VEC>(coef + C, c0, cb);
   load_coef<VEC>(coef + 2 * C, c0, ck);
+  load_coef<VEC>(coef + 3 * C, c0, sc);
+  load_coef<VEC>(coef + 4 * C, c0, sh);
   for (; i < nchunks; i += stride) {
     if (!fixed) {
       c0 = (int)(i % cc) * VEC;
       load_coef<VEC>(coef, c0, ca);
       load_coef<VEC>(coef + C, c0, cb);
       load_coef<VEC>(coef + 2 * C, c0, ck);
+      load_coef<VEC>(coef + 3 * C, c0, sc);
+      load_coef<VEC>(coef + 4 * C, c0, sh);
     }
     Vec16<T> vd, vx, vy, vo, vr;
     vd.load(dy + i * VEC);
     vx.load(x + i * VEC);
-    if (relu) vy.load(y + i * VEC);
+    if (relu == 1) vy.load(y + i * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float d = vd.get(j);
-      if (relu && !(vy.get(j) > 0.f)) d = 0.f;
-      vo.set(j, ca[j] * d + cb[j] * vx.get(j) + ck[j]);
+      const float xv = vx.get(j);
+      if (relu == 1 && !(vy.get(j) > 0.f)) d = 0.f;
+      if (relu == 2 && !(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
+      vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
       vr.set(j, d);
     }
     vo.store(dx + i * VEC);
@@ -291,7 +347,8 @@ void check_c(int C, int dtype) {
 
 template <int MODE>
 void col_reduce(const void* a, const void* x, const void* y, long M, int C, int dtype, const float* mean,
-                const float* invstd, int relu, float* partial, int nblk, hipStream_t s) {
+                const float* invstd, int relu, const float* scale, const float* shift, float* partial, int nblk,
+                hipStream_t s) {
   check_c(C, dtype);
   const int vec = dtype == kF32 ? 4 : 8;
   const int gy = ceil_div(C / vec, kBnThreads);
@@ -299,13 +356,13 @@ void col_reduce(const void* a, const void* x, const void* y, long M, int C, int 
   dim3 grid(nblk, gy);
   if (dtype == kF32)
     hipLaunchKernelGGL((col_reduce_kernel<float, MODE>), grid, dim3(kBnThreads), 0, s, (const float*)a,
-                       (const float*)x, (const float*)y, M, C, mean, invstd, relu, partial, rpb);
+                       (const float*)x, (const float*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
   else if (dtype == kBF16)
     hipLaunchKernelGGL((col_reduce_kernel<bf16_t, MODE>), grid, dim3(kBnThreads), 0, s, (const bf16_t*)a,
-                       (const bf16_t*)x, (const bf16_t*)y, M, C, mean, invstd, relu, partial, rpb);
+                       (const bf16_t*)x, (const bf16_t*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
   else
     hipLaunchKernelGGL((col_reduce_kernel<f16_t, MODE>), grid, dim3(kBnThreads), 0, s, (const f16_t*)a,
-                       (const f16_t*)x, (const f16_t*)y, M, C, mean, invstd, relu, partial, rpb);
+                       (const f16_t*)x, (const f16_t*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -330,13 +387,14 @@ void bn_fold_partials_launch(const float* partial, int nparts, int C, float* out
 }
 
 void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, int nblk, hipStream_t s) {
-  col_reduce<0>(x, nullptr, nullptr, M, C, dtype, nullptr, nullptr, 0, partial, nblk, s);
+  col_reduce<0>(x, nullptr, nullptr, M, C, dtype, nullptr, nullptr, 0, nullptr, nullptr, partial, nblk, s);
 }
 
 void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, int C, int dtype,
-                          const float* mean, const float* invstd, int relu, float* partial, int nblk,
-                          hipStream_t s) {
-  col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu, partial, nblk, s);
+                          const float* mean, const float* invstd, int relu, const float* scale,
+                          const float* shift, float* partial, int nblk, hipStream_t s) {
+  if (relu == 2 && (scale == nullptr || shift == nullptr)) throw std::invalid_argument("bn: relu mode 2 needs scale/shift");
+  col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu, scale, shift, partial, nblk, s);
 }
 
 void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* count_dev,
@@ -385,16 +443,29 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   DPA_CHECK_HIP(hipGetLastError());
 }
 
-void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
-                         int C, int dtype, const float* mean, const float* invstd,
-                         const float* gamma, const float* dgamma, const float* dbeta, double count,
-                         const float* count_dev, float* coef, int relu, hipStream_t s) {
+void bn_bwd_finalize_fused_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
+                                  const float* mean, const float* invstd, const float* gamma, double count,
+                                  float* coef, const float* scale, const float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_fused_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, partial, nparts, C, dgamma,
+                     dbeta, mean, invstd, gamma, (float)(1.0 / count), coef, scale, shift);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_bwd_coeffs_launch(const float* dgamma, const float* dbeta, const float* mean, const float* invstd,
+                          const float* gamma, double count, const float* count_dev, int C, float* coef,
+                          const float* scale, const float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, dgamma, dbeta, mean, invstd,
+                     gamma, (float)(1.0 / count), count_dev, C, coef, scale, shift);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+// coef: [5][C] from bn_bwd_finalize_fused_launch / bn_bwd_coeffs_launch
+void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M, int C,
+                         int dtype, const float* coef, int relu, hipStream_t s) {
   check_c(C, dtype);
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, dgamma, dbeta, mean, invstd,
-                     gamma, (float)(1.0 / count), count_dev, C, coef);
   const int grid = grid_for(nchunks);
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,

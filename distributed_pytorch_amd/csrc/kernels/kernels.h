@@ -12,6 +12,7 @@ struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
   const void* B;       // weights [N][ldb], reduction axis contiguous
   void* C;             // output rows of ldc elements
+  const void* R;       // optional tensor added in the epilogue (same dtype / rows as C): C = conv + R
   const float* bias;   // optional [N]
   float* stats;        // optional per-channel partial (sum, sum^2) slab [tiles_m][2][N]
   const int* taps;     // device int32 triples (dy, dx, wtap), ntaps entries
@@ -63,16 +64,22 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
                      const float* scale, const float* shift, int relu, hipStream_t s);
 // backward: dy masked by (y > 0) when relu; partial [nblk][2][C] = (sum dy, sum dy*xhat)
 void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, int C, int dtype,
-                          const float* mean, const float* invstd, int relu, float* partial, int nblk,
-                          hipStream_t s);
+                          const float* mean, const float* invstd, int relu /* 0 | 1: mask from y | 2: from x */,
+                          const float* scale, const float* shift, float* partial, int nblk, hipStream_t s);
 // sums partials -> dgamma, dbeta (fp32 [C]) and the two per-channel means used by the apply pass
 void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
                             hipStream_t s);
-void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M,
-                         int C, int dtype, const float* mean, const float* invstd,
-                         const float* gamma, const float* dgamma, const float* dbeta, double count,
-                         const float* count_dev, float* coef /* fp32 workspace [3][C] */, int relu,
-                         hipStream_t s);
+// fold partials -> dgamma, dbeta and (coef != nullptr) the apply coefficients [5][C], one launch
+void bn_bwd_finalize_fused_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
+                                  const float* mean, const float* invstd, const float* gamma, double count,
+                                  float* coef, const float* scale, const float* shift, hipStream_t s);
+// coefficients from (possibly all-reduced) sums; count_dev (optional) overrides count on the device
+void bn_bwd_coeffs_launch(const float* dgamma, const float* dbeta, const float* mean, const float* invstd,
+                          const float* gamma, double count, const float* count_dev, int C, float* coef,
+                          const float* scale, const float* shift, hipStream_t s);
+// dx = A*dy_m + B*x + K (coef rows 0..2), ReLU mask from y (relu 1) or from coef rows 3..4 and x (relu 2)
+void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M, int C,
+                         int dtype, const float* coef, int relu, hipStream_t s);
 
 // ------------------------------------------------------------------------------ pool.hip
 // idx (optional, uint8 per output element): tap code r*kw+q of the first arg-max, consumed by backward

@@ -215,31 +215,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// out[i] = beta*out[i] + sum_s slab[s][i].  A workgroup owns 64 float4 columns; its 4 waves each fold every
+// 4th slab (4 independent loads in flight per lane) and meet in LDS, so a small gradient with hundreds of
+// partial slabs is not one long dependent chain per thread.  Fixed summation order => deterministic.
 template <typename TO>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, long n,
                                                           TO* __restrict__ out, float beta) {
-  const long stride = (long)gridDim.x * blockDim.x * 4;
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
-    if (i + 4 <= n) {
-      float4 s = *reinterpret_cast<const float4*>(slab + i);
-      for (int k = 1; k < splits; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)k * n + i);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-      float r[4] = {s.x, s.y, s.z, s.w};
+  __shared__ float4 red[4][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + col) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i + 4 <= n) {
+    int k = sl;
+    for (; k + 12 < splits; k += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slab + (size_t)k * n + i);
+      const float4 v1 = *reinterpret_cast<const float4*>(slab + (size_t)(k + 4) * n + i);
+      const float4 v2 = *reinterpret_cast<const float4*>(slab + (size_t)(k + 8) * n + i);
+      const float4 v3 = *reinterpret_cast<const float4*>(slab + (size_t)(k + 12) * n + i);
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x);
+      acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z);
+      acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; k < splits; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)k * n + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  } else if (i < n) {       // ragged tail (n not a multiple of 4): scalar
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = sl; k < splits; k += 4)
+      for (int j = 0; j < 4 && i + j < n; ++j) t[j] += slab[(size_t)k * n + i + j];
+    acc = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  red[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    const float4 a = red[0][col], b = red[1][col], c = red[2][col], d = red[3][col];
+    const float r[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                        (a.w + b.w) + (c.w + d.w)};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float o = r[j];
-        if (beta != 0.f) o += beta * to_float(out[i + j]);
-        out[i + j] = from_float<TO>(o);
-      }
-    } else {
-      for (long e = i; e < n; ++e) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + e];
-        if (beta != 0.f) s += beta * to_float(out[e]);
-        out[e] = from_float<TO>(s);
-      }
+    for (int j = 0; j < 4; ++j) {
+      if (i + j >= n) break;
+      float o = r[j];
+      if (beta != 0.f) o += beta * to_float(out[i + j]);
+      out[i + j] = from_float<TO>(o);
     }
   }
 }
@@ -296,9 +315,7 @@ void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
 void slab_reduce_launch(const float* slab, int splits, long n, void* out, int out_dtype, float beta,
                         hipStream_t stream) {
   if (n <= 0) return;
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
+  const long blocks = ((n + 3) / 4 + 63) / 64;
   if (out_dtype == kF32)
     hipLaunchKernelGGL(slab_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, slab, splits, n,
                        reinterpret_cast<float*>(out), beta);

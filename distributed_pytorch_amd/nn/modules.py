@@ -43,10 +43,10 @@ class Conv2d(nn.Module):
             bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x: torch.Tensor, relu: bool = False, want_stats: bool = False):
+    def forward(self, x: torch.Tensor, relu: bool = False, want_stats: bool = False, skip: bool = False):
         return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu=relu,
                         w_lp=_amp.compute_copy(self.weight, x), want_stats=want_stats,
-                        needs_input_grad=self.needs_input_grad)
+                        needs_input_grad=self.needs_input_grad, skip=skip)
 
     def extra_repr(self) -> str:
         return "{}, {}, kernel_size={}, stride={}, padding={}, bias={}".format(
@@ -165,12 +165,18 @@ class Flatten(nn.Module):
         return x.reshape(x.shape[0], -1)
 
 
-def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool = True, residual=None):
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool = True, residual=None, skip: bool = False):
     """conv -> BN(+residual)(+ReLU).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
-    re-read for statistics."""
+    re-read for statistics.  ``skip=True`` -> ``(out, x_alias)`` (see ``F.conv2d``)."""
     fuse = F._on_gpu(x) and bn.training and bn.process_group is None
+    out = conv(x, want_stats=fuse, skip=skip)
+    alias = None
+    if skip:
+        out, alias = out
     if fuse:
-        y, stats = conv(x, want_stats=True)
-        return bn(y, relu=relu, residual=residual, stats=stats)
-    return bn(conv(x), relu=relu, residual=residual)
+        y, stats = out
+        res = bn(y, relu=relu, residual=residual, stats=stats)
+    else:
+        res = bn(out, relu=relu, residual=residual)
+    return (res, alias) if skip else res

@@ -41,18 +41,20 @@ def _pair(v) -> Tuple[int, int]:
 # ----------------------------------------------------------------------------- conv
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            stride=1, padding=0, *, relu: bool = False, w_lp: Optional[torch.Tensor] = None,
-           want_stats: bool = False, needs_input_grad: bool = True):
+           want_stats: bool = False, needs_input_grad: bool = True, skip: bool = False):
     """NHWC convolution.  ``weight`` is logical ``[K, C, R, S]`` (memory KRSC).
 
     ``w_lp``: optional low-precision compute copy of ``weight`` (AMP O1/O2);
     gradients still flow to ``weight``.  ``want_stats`` additionally returns the
     per-channel ``(sum, sumsq)`` of the output computed in the conv epilogue
     (feeds the fused BatchNorm).  ``needs_input_grad=False`` skips dgrad (stem).
+    ``skip=True`` returns ``(result, x_alias)``: feed ``x_alias`` to the residual branch and its
+    gradient is added inside this convolution's dgrad epilogue instead of a separate accumulate pass.
     """
     stride, padding = _pair(stride), _pair(padding)
     if _on_gpu(x):
         return _hip().conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats,
-                             needs_input_grad)
+                             needs_input_grad, skip)
     w = weight if w_lp is None else _StraightThroughCast.apply(weight, x.dtype)
     if w.dtype != x.dtype:
         w = w.to(x.dtype)
@@ -61,9 +63,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if relu:
         y = TF.relu(y)
     y = y.contiguous()
-    if want_stats:
-        return y, None
-    return y
+    out = (y, None) if want_stats else y
+    return (out, x) if skip else out
 
 
 class _StraightThroughCast(torch.autograd.Function):

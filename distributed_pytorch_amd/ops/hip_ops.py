@@ -219,13 +219,13 @@ def _conv_out(i, k, s, p):
 
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
-           scatter=None, relu=False, dtype=None, out_dtype=None):
+           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None):
     flags = (C().IGEMM_RELU if relu else 0)
     OHF = OWF = OSY = OSX = OY0 = OX0 = 0
     if scatter is not None:
         flags |= C().IGEMM_SCATTER
         OHF, OWF, OSY, OSX, OY0, OX0 = scatter
-    C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
+    C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
               _dt(dtype), _dt(out_dtype), _stream())
 
@@ -264,7 +264,7 @@ def _deliver(param, g):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad):
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip):
         x = x if x.is_contiguous() else x.contiguous()
         NB, IH, IW, Cx = x.shape
         K, Cw, R, S = weight.shape
@@ -291,11 +291,13 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y if relu else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y
+        # skip=True also returns an alias of the input for the residual branch: its gradient comes back into
+        # THIS node and is added inside the dgrad epilogue (no separate accumulate kernel, one rounding)
+        alias = x.view(x.shape) if skip else None
+        return y, stats, alias
 
     @staticmethod
-    def backward(ctx, dy, *unused):
+    def backward(ctx, dy, dstats=None, dalias=None):
         x, weight, y = ctx.saved_tensors
         (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
         NB, IH, IW, Cx = x.shape
@@ -309,17 +311,21 @@ class _ConvFn(torch.autograd.Function):
             C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
             dy = dym
         dx = dw = db = None
+        if dy is None:                      # only the alias was used downstream
+            return dalias, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0] and needs_input_grad:
-            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw))
+            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias)
+        elif dalias is not None:
+            dx = dalias
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
             db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv_dgrad(dy, weight, xshape, stride, padding):
+def conv_dgrad(dy, weight, xshape, stride, padding, accum=None):
     NB, IH, IW, Cx = xshape
     K, Cw, R, S = weight.shape
     sh, sw = stride
@@ -330,7 +336,13 @@ def conv_dgrad(dy, weight, xshape, stride, padding):
         raise ValueError("dgrad into a channel-padded input is not supported (stem has no input grad)")
     classes = _dgrad_classes(R, S, sh, sw, ph, pw)
     need_zero = any(len(t) == 0 for _, _, t in classes)
-    dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
+    if accum is not None:
+        accum = accum if accum.is_contiguous() else accum.contiguous()
+    if need_zero and accum is not None:
+        dx = accum.clone()                  # uncovered positions keep the other branch's gradient
+        accum = dx                          # covered ones accumulate in place (same thread reads then writes)
+    else:
+        dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
     for py, px, taps in classes:
         if not taps:
             continue
@@ -340,7 +352,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding):
         tt = _tap_table(dy.device, taps)
         scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
         _igemm(dy, wt, dx, None, None, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
-               SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype)
+               SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum)
     return dx
 
 
@@ -388,10 +400,12 @@ def _slice_channels(src: torch.Tensor, dst: torch.Tensor, keep: int) -> None:
     C().transpose_ktc(tmp.data_ptr(), dst.data_ptr(), keep, 1, n, 0, _dt(dst), _stream())
 
 
-def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad):
+def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad, skip=False):
     grad_sink.note_use(weight, bias)
-    return _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
-                         bool(needs_input_grad))
+    y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
+                                    bool(needs_input_grad), bool(skip))
+    out = (y, stats) if want_stats else y
+    return (out, alias) if skip else out
 
 
 # ------------------------------------------------------------------------------------------
@@ -461,9 +475,12 @@ class _BNFn(torch.autograd.Function):
         y = torch.empty_like(x)
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
                      coef[3].data_ptr(), 1 if relu else 0, st)
-        ctx.save_for_backward(x, y if relu else None, weight, coef, count_dev)
+        # ReLU mask in backward: recomputed from x (scale*x + shift > 0) when there is no residual, so the
+        # output is neither saved by this op nor read again; with a residual it comes from y
+        relu_mode = 0 if not relu else (1 if residual is not None else 2)
+        ctx.save_for_backward(x, y if relu_mode == 1 else None, weight, coef, count_dev)
         ctx.bias_ref = bias
-        ctx.cfg = (relu, residual is not None, group, count)
+        ctx.cfg = (relu_mode, residual is not None, group, count)
         return y
 
     @staticmethod
@@ -478,8 +495,8 @@ class _BNFn(torch.autograd.Function):
         nblk = C().bn_partial_rows(M, Cc)
         part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
         C().bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), _p(y), M, Cc, _dt(x), coef[0].data_ptr(),
-                          coef[1].data_ptr(), 1 if relu else 0, part.data_ptr(), nblk, st)
-        part = _fold(part, Cc)
+                          coef[1].data_ptr(), relu, coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(),
+                          nblk, st)
         # local [dgamma, dbeta]: written straight into the parameters' gradient views when possible
         bias_p = ctx.bias_ref
         sw_, sb_ = grad_sink.sink_of(weight), grad_sink.sink_of(bias_p)
@@ -490,19 +507,24 @@ class _BNFn(torch.autograd.Function):
         else:
             sums = torch.empty((2, Cc), dtype=torch.float32, device=dev)
             dg_t, db_t = sums[0], sums[1]
-        C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, dg_t.data_ptr(), db_t.data_ptr(), st)
-        gdg, gdb = dg_t, db_t
-        if _group_size(group) > 1:
+        g32 = _f32(weight.detach())
+        wk = torch.empty((5, Cc), dtype=torch.float32, device=dev)
+        sync = _group_size(group) > 1
+        # fold the partial slab (wide first stage when it is long) and, non-sync, emit the apply coefficients
+        part = _fold(part, Cc)
+        C().bn_bwd_finalize_fused(part.data_ptr(), part.shape[0], Cc, dg_t.data_ptr(), db_t.data_ptr(),
+                                  coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), count,
+                                  0 if sync else wk.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+        if sync:
             gs = torch.stack([dg_t, db_t])
             _all_reduce_sum(gs, group)
-            gdg, gdb = gs[0], gs[1]
-        g32 = _f32(weight.detach())
+            C().bn_bwd_coeffs(gs[0].data_ptr(), gs[1].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                              g32.data_ptr(), count, _p(count_dev), Cc, wk.data_ptr(), coef[2].data_ptr(),
+                              coef[3].data_ptr(), st)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        wk = torch.empty((3, Cc), dtype=torch.float32, device=dev)
         C().bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), _p(dres), M, Cc, _dt(x),
-                         coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), gdg.data_ptr(),
-                         gdb.data_ptr(), count, _p(count_dev), wk.data_ptr(), 1 if relu else 0, st)
+                         wk.data_ptr(), relu, st)
         if direct:
             sw_.delivered()
             sb_.delivered()
