@@ -120,7 +120,8 @@ def main():
     ips = world * args.batch_size * args.steps / dt
     if rank == 0:
         print(json.dumps({
-            "metric": "images/sec (whole job) ResNet-50 AMP training" +
+            "metric": "images/sec (whole job) %s %s training" % (
+                {"resnet50": "ResNet-50"}.get(args.arch, args.arch), "AMP" if args.dtype != "fp32" else "fp32") +
                       (" [stock-PyTorch-ops baseline]" if F._TORCH_BASELINE else ""),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),

@@ -68,6 +68,7 @@ struct FastDiv {
 inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv f;
   f.d = d;
+  if (d == 0) throw std::invalid_argument("fastdiv: zero divisor (empty output grid?)");
   if (d == 1) {
     f.magic = 0;
     f.shift = 0;

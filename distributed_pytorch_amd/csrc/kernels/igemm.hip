@@ -19,6 +19,8 @@
 // (nd_imagenet.py:291,302; imagenet_ddp_apex.py:372,381) -- SURVEY.md N-K1, N-K2, N-K10.
 #include "../common.h"
 #include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -360,7 +362,9 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
     attr_done = true;
   }
   const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  if (getenv("DPA_DEBUG")) { fprintf(stderr, "  launch tiles=%ld lds=%d nk=%d\n", tiles, lds, nk); fflush(stderr); }
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  if (getenv("DPA_DEBUG")) { fprintf(stderr, "  launched\n"); fflush(stderr); }
 }
 
 template <typename T, typename TOut>
@@ -382,6 +386,11 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
 }  // namespace
 
 void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream) {
+  if (getenv("DPA_DEBUG")) {
+    fprintf(stderr, "igemm M=%d N=%d Cred=%d ntaps=%d lda=%d ldb=%d ldc=%d IH=%d IW=%d S=%d,%d flags=%d dt=%d/%d\n", p.M, p.N,
+            p.Cred, p.ntaps, p.lda, p.ldb, p.ldc, p.IH, p.IW, p.SY, p.SX, p.flags, dtype, out_dtype);
+    fflush(stderr);
+  }
   const int vec = dtype == kF32 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0) return;
   if (p.Cred % vec != 0 || p.lda % vec != 0 || p.ldb % vec != 0)

@@ -55,6 +55,8 @@ class _ImageNetCNN(nn.Module):
         if x.dtype == torch.uint8:
             layout = "nhwc" if x.shape[-1] in (1, 3) else "nchw"
             return F.normalize_u8(x, dtype, pad, input_layout=layout)
+        if getattr(x, "_dpa_nhwc", False):      # already normalised NHWC (StreamPrefetcher)
+            return x
         return F.to_nhwc(x, dtype, pad)
 
     def forward(self, x):

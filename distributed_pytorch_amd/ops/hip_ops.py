@@ -273,6 +273,8 @@ class _ConvFn(torch.autograd.Function):
         sh, sw = stride
         ph, pw = padding
         OH, OW = _conv_out(IH, R, sh, ph), _conv_out(IW, S, sw, pw)
+        if OH <= 0 or OW <= 0:
+            raise ValueError("conv2d: input %s too small for kernel %s" % (tuple(x.shape), (R, S)))
         wc = conv_weight(weight, x.dtype, Cx)
         y = torch.empty((NB, OH, OW, K), dtype=x.dtype, device=x.device)
         M = NB * OH * OW
@@ -425,9 +427,14 @@ def _fold(part: torch.Tensor, C_: int, limit: int = 64) -> torch.Tensor:
     return out
 
 
+_FORCE_SYNC_PATH = False     # tests: take the SyncBN code path (all-reduce of a 1-rank group) on one GPU
+
+
 def _group_size(group) -> int:
     import torch.distributed as dist
 
+    if _FORCE_SYNC_PATH and group is not None:
+        return 2
     if group is None or not (dist.is_available() and dist.is_initialized()):
         return 1
     return dist.get_world_size(None if group == "world" else group)
@@ -436,7 +443,8 @@ def _group_size(group) -> int:
 def _all_reduce_sum(t: torch.Tensor, group) -> None:
     import torch.distributed as dist
 
-    dist.all_reduce(t, group=None if group == "world" else group)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, group=None if group == "world" else group)
 
 
 class _BNFn(torch.autograd.Function):

@@ -76,3 +76,69 @@ def test_bf16_training_reduces_loss_and_tracks_fp32():
     assert curves["O0"][-1] < 0.5 * curves["O0"][0], curves["O0"]
     assert curves["O2"][-1] < 0.5 * curves["O2"][0], curves["O2"]
     assert abs(curves["O0"][0] - curves["O2"][0]) < 0.1
+
+
+def test_fp16_dynamic_loss_scaling_trains_and_recovers_from_overflow():
+    """fp16 O2 with Apex-style dynamic scaling: an injected inf gradient skips the step and halves the scale
+    on the device (no host sync in the step), then training continues."""
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.ops import functional as F
+    from distributed_pytorch_amd.optim import FusedSGD
+
+    torch.manual_seed(0)
+    amp.state().reset()
+    model = models.create_model("resnet18", num_classes=16).cuda().train()
+    opt = FusedSGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    model, opt = amp.initialize(model, opt, opt_level="O2", dtype="fp16", loss_scale="dynamic")
+    scaler = amp.state().scaler
+    assert scaler.loss_scale() == 2.0 ** 16
+    x = torch.randint(0, 256, (16, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    t = torch.randint(0, 10, (16,), device="cuda")
+    losses = []
+    for it in range(14):
+        out = model(x)
+        assert out.dtype == torch.float32
+        loss, _ = F.loss_and_metrics(out, t)
+        opt.zero_grad()
+        with amp.scale_loss(loss, opt) as s:
+            s.backward()
+            if it == 3:
+                model.fc.weight.grad[0, 0] = float("inf")          # poison one gradient element
+        before = model.fc.weight.detach().clone()
+        opt.step()
+        if it == 3:
+            assert torch.equal(before, model.fc.weight.detach())   # whole step skipped
+        losses.append(float(loss))
+    assert scaler.loss_scale() < 2.0 ** 16                          # backed off at least once
+    assert losses[-1] < 0.6 * losses[0], losses
+    amp.state().reset()
+
+
+def test_syncbn_gpu_path_equals_plain_bn_on_one_rank():
+    """The SyncBN branch (packed [sum, sumsq, n] all-reduce, device-side count, separate coefficient
+    kernel) must reproduce plain BN when the group has a single rank."""
+    from distributed_pytorch_amd.ops import functional as F, hip_ops
+
+    torch.manual_seed(3)
+    C = 64
+    xs = [(torch.randn(4, 6, 6, C, device="cuda") * 2 + 1).to(torch.bfloat16).requires_grad_(True) for _ in range(2)]
+    ws = [(torch.rand(C, device="cuda") + 0.5).requires_grad_(True) for _ in range(2)]
+    bs = [torch.randn(C, device="cuda").requires_grad_(True) for _ in range(2)]
+    with torch.no_grad():
+        xs[1].copy_(xs[0]); ws[1].copy_(ws[0]); bs[1].copy_(bs[0])
+    outs, stats = [], []
+    for i, group in enumerate((None, "world")):
+        hip_ops._FORCE_SYNC_PATH = group is not None
+        try:
+            rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+            nbt = torch.zeros((), dtype=torch.long, device="cuda")
+            y = F.batch_norm(xs[i], ws[i], bs[i], rm, rv, nbt, True, 0.1, 1e-5, relu=True, group=group)
+            y.float().square().sum().backward()
+            outs.append(y.detach().float())
+            stats.append((rm, rv))
+        finally:
+            hip_ops._FORCE_SYNC_PATH = False
+    assert torch.allclose(outs[0], outs[1], atol=1e-2)
+    assert torch.allclose(stats[0][0], stats[1][0], atol=1e-5) and torch.allclose(stats[0][1], stats[1][1], atol=1e-4)
+    for a, b in ((xs[0].grad, xs[1].grad), (ws[0].grad, ws[1].grad), (bs[0].grad, bs[1].grad)):
+        assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2 * float(a.float().abs().max()))
