@@ -40,12 +40,82 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def sweep(args, hip_ops):
+    """fprop / dgrad time of every tile configuration (igemm_force_config) per layer shape."""
+    C = hip_ops.C()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
+    N = args.batch
+    ncfg = C.igemm_num_configs()
+    print("ms per call; columns = config ids 0..%d, 'a' = automatic choice" % (ncfg - 1))
+    totals = {}
+    for (H, Cin, Cout, k, s, p, cnt) in R50:
+        if Cin % 8:
+            continue
+        OH = (H + 2 * p - k) // s + 1
+        x = torch.randn(N, H, H, Cin, device="cuda").to(dt)
+        w = (torch.randn(Cout, Cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, OH, OH, Cout, device="cuda").to(dt)
+        for kind, fn in (("fprop", lambda: hip_ops.conv2d(x, w, None, (s, s), (p, p), False, None, True, False)),
+                         ("dgrad", lambda: hip_ops.conv_dgrad(dy, w, tuple(x.shape), (s, s), (p, p)))):
+            ts = []
+            for cfg in list(range(ncfg)) + [-1]:
+                C.igemm_force_config(cfg)
+                ts.append(timeit(fn, 6) * 1e3)
+            C.igemm_force_config(-1)
+            best = min(range(ncfg), key=lambda i: ts[i])
+            totals.setdefault(kind, [0.0, 0.0])
+            totals[kind][0] += ts[-1] * cnt
+            totals[kind][1] += ts[best] * cnt
+            print("%3dx%-3d %4d->%-4d k%d s%d x%d %s  %s  a=%.3f best=%d (%.3f)" % (
+                H, H, Cin, Cout, k, s, cnt, kind, " ".join("%.3f" % t for t in ts[:-1]), ts[-1], best, ts[best]),
+                flush=True)
+    for kind, (a, b) in totals.items():
+        print("weighted %s: auto %.2f ms, best-per-layer %.2f ms" % (kind, a, b))
+
+
+def sweep_wgrad(args, hip_ops):
+    C = hip_ops.C()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    N = args.batch
+    ncfg = C.wgrad_num_configs()
+    C.wgrad_set_target_blocks(args.target_blocks)
+    print("wgrad ms per call (kernel + slab fold); columns = config ids 0..%d, 'a' = automatic; target blocks %d" % (
+        ncfg - 1, args.target_blocks))
+    tot = [0.0, 0.0]
+    for (H, Cin, Cout, k, s, p, cnt) in R50:
+        Cx = Cin if Cin % 8 == 0 else 8
+        OH = (H + 2 * p - k) // s + 1
+        x = torch.randn(N, H, H, Cx, device="cuda").to(dt)
+        w = (torch.randn(Cout, Cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, OH, OH, Cout, device="cuda").to(dt)
+        fn = lambda: hip_ops.conv_wgrad(dy, x, w, (s, s), (p, p))
+        ts = []
+        for cfg in list(range(ncfg)) + [-1]:
+            C.wgrad_force_config(cfg)
+            ts.append(timeit(fn, 6) * 1e3)
+        C.wgrad_force_config(-1)
+        best = min(range(ncfg), key=lambda i: ts[i])
+        tot[0] += ts[-1] * cnt
+        tot[1] += ts[best] * cnt
+        print("%3dx%-3d %4d->%-4d k%d s%d x%d  %s  a=%.3f best=%d (%.3f)" % (
+            H, H, Cin, Cout, k, s, cnt, " ".join("%.3f" % t for t in ts[:-1]), ts[-1], best, ts[best]), flush=True)
+    print("weighted wgrad: auto %.2f ms, best-per-layer %.2f ms" % tuple(tot))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--sweep", action="store_true", help="time every igemm tile configuration per layer")
+    ap.add_argument("--target-blocks", type=int, default=768)
+    ap.add_argument("--sweep-wgrad", action="store_true", help="time every wgrad tile configuration per layer")
     args = ap.parse_args()
     from distributed_pytorch_amd.ops import hip_ops
+
+    if args.sweep:
+        return sweep(args, hip_ops)
+    if args.sweep_wgrad:
+        return sweep_wgrad(args, hip_ops)
 
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     es = 2 if dt != torch.float32 else 4

@@ -46,7 +46,13 @@ PYBIND11_MODULE(_C, m) {
           igemm_launch(p, dtype, out_dtype, st(stream));
         });
   m.def("igemm_tile_m", &igemm_tile_m);
+  m.def("igemm_stats_rows", &igemm_stats_rows);
+  m.def("igemm_force_config", &igemm_force_config);
+  m.def("igemm_num_configs", &igemm_num_configs);
 
+  m.def("wgrad_force_config", &wgrad_force_config);
+  m.def("wgrad_num_configs", &wgrad_num_configs);
+  m.def("wgrad_set_target_blocks", &wgrad_set_target_blocks);
   m.def("wgrad_choose_splits", [](long M, int N, int Ktot, int dtype) {
     int pps = 0;
     const int s = wgrad_choose_splits(M, N, Ktot, dtype, &pps);

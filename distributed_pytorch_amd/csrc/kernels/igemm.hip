@@ -19,10 +19,9 @@
 // (nd_imagenet.py:291,302; imagenet_ddp_apex.py:372,381) -- SURVEY.md N-K1, N-K2, N-K10.
 #include "../common.h"
 #include "kernels.h"
-#include <cstdio>
-#include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace dpa {
 
@@ -56,10 +55,159 @@ template <> struct Mma<float> {
   }
 };
 
+// ---- epilogue shared by both main loops: registers -> LDS tile [pixel][channel] -> 16-byte global
+// stores (+ bias, ReLU, fused accumulate, BatchNorm partial statistics).  All waves must be past their
+// last read of the staging buffers (barrier) and have no LDS-DMA in flight when they enter.
+template <typename TOut, int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&acc)[BN / 64][BM / 64],
+                                               unsigned char* smem, int m0, int n0, int mt) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int LDE = BN * (int)sizeof(TOut) + 16;   // epilogue tile row bytes
+  constexpr int CE = BN * (int)sizeof(TOut) / 16;    // 16-byte chunks per epilogue row
+  constexpr int E_IT = BM * CE / 256;
+  constexpr int VECO = 16 / (int)sizeof(TOut);
+  static_assert(E_IT >= 1 && 256 % CE == 0, "chunk mapping");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte global stores -----------
+  // acc[a][b][r]: channel = wn*WTN + a*32 + (r&3) + 8*(r>>2) + 4*lh, pixel = wm*WTM + b*32 + l31
+  unsigned char* se = smem;
+  const bool relu = p.flags & kIgemmRelu;
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cch = wn * WTN + a * 32 + 8 * g + 4 * lh;
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[j] = (n0 + cch + j < p.N) ? p.bias[n0 + cch + j] : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        const int pix = wm * WTM + b * 32 + l31;
+        TOut o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[a][b][4 * g + j] + bs[j];
+          if (relu) v = fmaxf(v, 0.f);
+          o[j] = from_float<TOut>(v);
+        }
+        unsigned char* dst = se + pix * LDE + cch * sizeof(TOut);
+        if (sizeof(TOut) == 2) {
+          uint2 w;
+          __builtin_memcpy(&w, o, 8);
+          *reinterpret_cast<uint2*>(dst) = w;
+        } else {
+          uint4 w;
+          __builtin_memcpy(&w, o, 16);
+          *reinterpret_cast<uint4*>(dst) = w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int ce = tid % CE;
+  const int ncol = n0 + ce * VECO;
+  float s1[VECO], s2[VECO];
+#pragma unroll
+  for (int j = 0; j < VECO; ++j) s1[j] = s2[j] = 0.f;
+  char* __restrict__ Cg = reinterpret_cast<char*>(p.C);
+#pragma unroll
+  for (int i = 0; i < E_IT; ++i) {
+    const int row = (tid + i * 256) / CE;
+    const uint32_t m = m0 + row;
+    if (m >= (uint32_t)p.M || ncol >= p.N) continue;
+    Vec16<TOut> v;
+    v.load(se + row * LDE + ce * 16);
+    size_t orow = m;
+    if (p.flags & kIgemmScatter) {
+      const uint32_t n = fdiv(m, p.div_ohow);
+      const uint32_t rem = m - n * p.div_ohow.d;
+      const uint32_t oy = fdiv(rem, p.div_ow);
+      const uint32_t ox = rem - oy * p.div_ow.d;
+      orow = ((size_t)n * p.OHF + oy * p.OSY + p.OY0) * p.OWF + ox * p.OSX + p.OX0;
+    }
+    const size_t goff = (orow * p.ldc + ncol) * sizeof(TOut);
+    char* dst = Cg + goff;
+    if (p.R != nullptr) {      // fused accumulate (gradient of a tensor with two consumers): one rounding
+      const char* rsrc = reinterpret_cast<const char*>(p.R) + goff;
+      if (ncol + VECO <= p.N) {
+        Vec16<TOut> r;
+        r.load(rsrc);
+#pragma unroll
+        for (int j = 0; j < VECO; ++j) v.set(j, v.get(j) + r.get(j));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VECO; ++j) {   // constant j: keeps v in registers (a runtime index sends it to scratch)
+          if (ncol + j < p.N) {
+            TOut t = *reinterpret_cast<const TOut*>(rsrc + j * sizeof(TOut));
+            v.set(j, v.get(j) + to_float(t));
+          }
+        }
+      }
+    }
+    if (ncol + VECO <= p.N) {
+      v.store(dst);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VECO; ++j)
+        if (ncol + j < p.N) *reinterpret_cast<TOut*>(dst + j * sizeof(TOut)) = from_float<TOut>(v.get(j));
+    }
+    if (p.stats != nullptr) {
+#pragma unroll
+      for (int j = 0; j < VECO; ++j) {
+        const float f = v.get(j);
+        s1[j] += f;
+        s2[j] += f * f;
+      }
+    }
+  }
+  if (p.stats != nullptr) {
+    // threads sharing a chunk column: tid = ce (mod CE). reduce inside the wave, then over waves.
+#pragma unroll
+    for (int j = 0; j < VECO; ++j) {
+#pragma unroll
+      for (int o = 32; o >= CE; o >>= 1) {
+        s1[j] += __shfl_xor(s1[j], o, 64);
+        s2[j] += __shfl_xor(s2[j], o, 64);
+      }
+    }
+    // LDS-only barrier: __syncthreads() would first drain the tile's global stores (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // epilogue tile fully consumed
+    asm volatile("" ::: "memory");
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+    if (lane < CE) {
+#pragma unroll
+      for (int j = 0; j < VECO; ++j) {
+        red[(wave * 2 + 0) * BN + ce * VECO + j] = s1[j];
+        red[(wave * 2 + 1) * BN + ce * VECO + j] = s2[j];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int which = c / BN, col = c - which * BN;
+      if (n0 + col < p.N) {
+        const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
+                        red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
+        p.stats[((size_t)mt * 2 + which) * p.N + n0 + col] = s;
+      }
+    }
+  }
+}
+
 // BM: pixel rows per block, BN: output channels per block, BKB: bytes of K per row per K tile.
 // 256 threads = 2 (pixel) x 2 (channel) waves.
-template <typename T, typename TOut, int BM, int BN, int BKB, bool ALIGNED>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED>
+__global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
   constexpr int CPR = BKB / 16;          // 16-byte chunks per tile row
@@ -69,12 +217,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   constexpr int STAGE = (BM + BN) * LDR;
-  constexpr int LDE = BN * (int)sizeof(TOut) + 16;   // epilogue tile row bytes
-  constexpr int CE = BN * (int)sizeof(TOut) / 16;    // 16-byte chunks per epilogue row
-  constexpr int E_IT = BM * CE / 256;
-  constexpr int VECO = 16 / (int)sizeof(TOut);
-  static_assert(A_IT >= 1 && B_IT >= 1 && MI >= 1 && NI >= 1 && E_IT >= 1, "tile too small");
-  static_assert(256 % CPR == 0 && 256 % CE == 0, "chunk mapping");
+  static_assert(A_IT >= 1 && B_IT >= 1 && MI >= 1 && NI >= 1, "tile too small");
+  static_assert(256 % CPR == 0, "chunk mapping");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -212,136 +356,237 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte global stores -----------
-  // acc[a][b][r]: channel = wn*WTN + a*32 + (r&3) + 8*(r>>2) + 4*lh, pixel = wm*WTM + b*32 + l31
-  unsigned char* se = smem;
-  const bool relu = p.flags & kIgemmRelu;
-#pragma unroll
-  for (int a = 0; a < NI; ++a) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cch = wn * WTN + a * 32 + 8 * g + 4 * lh;
-      float bs[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] = (n0 + cch + j < p.N) ? p.bias[n0 + cch + j] : 0.f;
-      }
-#pragma unroll
-      for (int b = 0; b < MI; ++b) {
-        const int pix = wm * WTM + b * 32 + l31;
-        TOut o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[a][b][4 * g + j] + bs[j];
-          if (relu) v = fmaxf(v, 0.f);
-          o[j] = from_float<TOut>(v);
-        }
-        unsigned char* dst = se + pix * LDE + cch * sizeof(TOut);
-        if (sizeof(TOut) == 2) {
-          uint2 w;
-          __builtin_memcpy(&w, o, 8);
-          *reinterpret_cast<uint2*>(dst) = w;
-        } else {
-          uint4 w;
-          __builtin_memcpy(&w, o, 16);
-          *reinterpret_cast<uint4*>(dst) = w;
-        }
-      }
-    }
-  }
-  __syncthreads();
+  igemm_epilogue<TOut, BM, BN>(p, acc, smem, m0, n0, mt);
+}
 
-  const int ce = tid % CE;
-  const int ncol = n0 + ce * VECO;
-  float s1[VECO], s2[VECO];
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA main loop: the same tile computation, staged with global_load_lds_dwordx4 into an S-deep ring
+// of unpadded LDS tiles so that S-1 K tiles (not one) are in flight per workgroup while one is consumed --
+// the register-staged loop above is bound by bytes in flight per CU on the memory-bound layers.
+//  * one wave-instruction moves 64 x 16 B = 1 KiB: RPI = 1024/BKB whole tile rows, lane -> (row, chunk)
+//  * the LDS image is lane-linear, so the bank swizzle lives on the SOURCE address and on the fragment
+//    read:  physical chunk = logical chunk ^ ((row / (256/BKB)) & (BKB/16 - 1))   (conflict-free b128 reads)
+//  * out-of-image taps / rows beyond M or N read a zero page instead of being zero-filled in registers
+//  * one raw s_barrier per K tile; the wave waits only for ITS OWN pieces of tile kt (counted vmcnt) before
+//    the barrier, leaving the S-2 younger tiles in flight.  A stage is re-filled one barrier after its last read.
+// Needs Cred % BK == 0 (a K tile never straddles taps).
+__device__ uint4 g_zero_page[4];
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int OFF> __device__ __forceinline__ uint4 lds_read_b128_asm(uint32_t addr) {
+  uint4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+// One K tile of the ring: fragments of step ks+1 are requested before the MFMAs of step ks are issued and
+// land while they run.  Waits are lgkmcnt(0) (robust against any scalar load the compiler interleaves), each
+// followed by sched_barrier(0) so no MFMA is hoisted above the wait that produces its operands.
+template <typename T, int NI, int MI, int KS, int BKB>
+__device__ __forceinline__ void ring_tile_mma(f32x16_t (&acc)[NI][MI], const uint32_t (&offA)[KS],
+                                              const uint32_t (&offB)[KS], uint32_t sbase) {
+  static_assert(NI <= 2 && MI <= 2, "immediate offsets below are written for <= 2 fragments per operand");
+  uint4 wf[2][2], xf[2][2];
+  wf[0][0] = lds_read_b128_asm<0>(offB[0] + sbase);
+  if (NI > 1) wf[0][1] = lds_read_b128_asm<32 * BKB>(offB[0] + sbase);
+  xf[0][0] = lds_read_b128_asm<0>(offA[0] + sbase);
+  if (MI > 1) xf[0][1] = lds_read_b128_asm<32 * BKB>(offA[0] + sbase);
 #pragma unroll
-  for (int j = 0; j < VECO; ++j) s1[j] = s2[j] = 0.f;
-  char* __restrict__ Cg = reinterpret_cast<char*>(p.C);
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = ks & 1, n = c ^ 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < KS) {
+      wf[n][0] = lds_read_b128_asm<0>(offB[ks + 1 < KS ? ks + 1 : 0] + sbase);
+      if (NI > 1) wf[n][1] = lds_read_b128_asm<32 * BKB>(offB[ks + 1 < KS ? ks + 1 : 0] + sbase);
+      xf[n][0] = lds_read_b128_asm<0>(offA[ks + 1 < KS ? ks + 1 : 0] + sbase);
+      if (MI > 1) xf[n][1] = lds_read_b128_asm<32 * BKB>(offA[ks + 1 < KS ? ks + 1 : 0] + sbase);
+    }
 #pragma unroll
-  for (int i = 0; i < E_IT; ++i) {
-    const int row = (tid + i * 256) / CE;
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) Mma<T>::run(acc[a][b], wf[c][a], xf[c][b]);
+  }
+}
+
+template <typename T, typename TOut, int BM, int BN, int BKB, int S, int MINB>
+__global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams p) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BK = BKB / (int)sizeof(T);
+  constexpr int CPR = BKB / 16;            // 16-byte chunks per tile row (4 or 8)
+  constexpr int RPI = 64 / CPR;            // tile rows per wave-instruction
+  constexpr int A_INST = BM / RPI / 4, B_INST = BN / RPI / 4;
+  constexpr int IPT = A_INST + B_INST;     // LDS-DMA instructions per wave per K tile
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int SWR = 256 / BKB;           // tile rows per 256-byte LDS bank row
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(A_INST >= 1 && B_INST >= 1 && MI >= 1 && NI >= 1, "tile too small");
+  static_assert(S >= 2 && S <= 4 && (BKB == 64 || BKB == 128), "ring depth / K tile");
+  static_assert((S - 1) * IPT < 64, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const uint32_t tiles_n = (p.N + BN - 1) / BN;
+  const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / tiles_n, nt = lid - mt * tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  const int r_in = lane / CPR, cphys = lane % CPR;
+  int iy0[A_INST], ix0[A_INST], pbase[A_INST], acol[A_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int row = (wave * A_INST + i) * RPI + r_in;
+    acol[i] = (cphys ^ ((row / SWR) & (CPR - 1))) * VEC;
     const uint32_t m = m0 + row;
-    if (m >= (uint32_t)p.M || ncol >= p.N) continue;
-    Vec16<TOut> v;
-    v.load(se + row * LDE + ce * 16);
-    size_t orow = m;
-    if (p.flags & kIgemmScatter) {
+    if (m < (uint32_t)p.M) {
       const uint32_t n = fdiv(m, p.div_ohow);
       const uint32_t rem = m - n * p.div_ohow.d;
       const uint32_t oy = fdiv(rem, p.div_ow);
       const uint32_t ox = rem - oy * p.div_ow.d;
-      orow = ((size_t)n * p.OHF + oy * p.OSY + p.OY0) * p.OWF + ox * p.OSX + p.OX0;
-    }
-    const size_t goff = (orow * p.ldc + ncol) * sizeof(TOut);
-    char* dst = Cg + goff;
-    if (p.R != nullptr) {      // fused accumulate (gradient of a tensor with two consumers): one rounding
-      const char* rsrc = reinterpret_cast<const char*>(p.R) + goff;
-      if (ncol + VECO <= p.N) {
-        Vec16<TOut> r;
-        r.load(rsrc);
-#pragma unroll
-        for (int j = 0; j < VECO; ++j) v.set(j, v.get(j) + r.get(j));
-      } else {
-        for (int j = 0; j < VECO && ncol + j < p.N; ++j) {
-          TOut t;
-          __builtin_memcpy(&t, rsrc + j * sizeof(TOut), sizeof(TOut));
-          v.set(j, v.get(j) + to_float(t));
-        }
-      }
-    }
-    if (ncol + VECO <= p.N) {
-      v.store(dst);
+      iy0[i] = oy * p.SY;
+      ix0[i] = ox * p.SX;
+      pbase[i] = n * p.IH * p.IW;
     } else {
-      for (int j = 0; j < VECO && ncol + j < p.N; ++j)
-        __builtin_memcpy(dst + j * sizeof(TOut), reinterpret_cast<const char*>(&v.raw) + j * sizeof(TOut),
-                         sizeof(TOut));
-    }
-    if (p.stats != nullptr) {
-#pragma unroll
-      for (int j = 0; j < VECO; ++j) {
-        const float f = v.get(j);
-        s1[j] += f;
-        s2[j] += f * f;
-      }
+      iy0[i] = -(1 << 28);
+      ix0[i] = 0;
+      pbase[i] = 0;
     }
   }
-  if (p.stats != nullptr) {
-    // threads sharing a chunk column: tid = ce (mod CE). reduce inside the wave, then over waves.
+  size_t boff[B_INST];
+  bool bok[B_INST];
 #pragma unroll
-    for (int j = 0; j < VECO; ++j) {
+  for (int i = 0; i < B_INST; ++i) {
+    const int row = (wave * B_INST + i) * RPI + r_in;
+    const int n = n0 + row;
+    bok[i] = n < p.N;
+    boff[i] = (size_t)(bok[i] ? n : 0) * p.ldb + (cphys ^ ((row / SWR) & (CPR - 1))) * VEC;
+  }
+
+  const int kpt = p.Cred / BK;
+  const int nk = p.ntaps * kpt;
+
+  // The tap table lives in lanes (tap t in lane t, ntaps <= 64) and is fetched with v_readlane: an ordinary
+  // global load inside the loop would make the compiler drain the whole ring with vmcnt(0) every K tile.
+  int tdy = 0, tdx = 0, twt = 0;
+  if (lane < p.ntaps) {
+    tdy = p.taps[3 * lane + 0];
+    tdx = p.taps[3 * lane + 1];
+    twt = p.taps[3 * lane + 2];
+  }
+
+  auto issue = [&](int t, int c0, int stage) {
+    const int dy = __builtin_amdgcn_readlane(tdy, t);
+    const int dx = __builtin_amdgcn_readlane(tdx, t);
+    const size_t kB = (size_t)__builtin_amdgcn_readlane(twt, t) * p.Cred + c0;
+    unsigned char* sa = smem + stage * STAGE;
+    unsigned char* sb = sa + BM * BKB;
 #pragma unroll
-      for (int o = 32; o >= CE; o >>= 1) {
-        s1[j] += __shfl_xor(s1[j], o, 64);
-        s2[j] += __shfl_xor(s2[j], o, 64);
-      }
+    for (int i = 0; i < A_INST; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const size_t off = ((size_t)(pbase[i] + iy * p.IW + ix) * p.lda + c0 + acol[i]) * sizeof(T);
+      const char* src = ok ? Ag + off : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(sa + (wave * A_INST + i) * 1024), 16, 0, 0);
     }
-    // LDS-only barrier: __syncthreads() would first drain the tile's global stores (vmcnt(0))
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // epilogue tile fully consumed
-    asm volatile("" ::: "memory");
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
-    if (lane < CE) {
 #pragma unroll
-      for (int j = 0; j < VECO; ++j) {
-        red[(wave * 2 + 0) * BN + ce * VECO + j] = s1[j];
-        red[(wave * 2 + 1) * BN + ce * VECO + j] = s2[j];
-      }
+    for (int i = 0; i < B_INST; ++i) {
+      const char* src = bok[i] ? Bg + (boff[i] + kB) * sizeof(T) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)(sb + (wave * B_INST + i) * 1024), 16, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  f32x16_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // (tap, channel offset) of the next tile to issue
+  int it = 0, ic = 0, issued = 0;
+  auto issue_next = [&](int stage) {
+    issue(it, ic, stage);
+    ++issued;
+    ic += BK;
+    if (ic == p.Cred) {
+      ic = 0;
+      ++it;
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) issue_next(s);
+
+  // Fragment reads are inline asm: a compiler-visible ds_read after an LDS-DMA makes hipcc wait vmcnt(0).
+  constexpr int KS = BKB / 32;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int fx = (l31 / SWR) & (CPR - 1);     // swizzle term of this lane's fragment rows (period 16 rows)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  uint32_t offA[KS], offB[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int coff = ((ks * 2 + lh) ^ fx) * 16;
+    offA[ks] = lds0 + (wm * WTM + l31) * BKB + coff;
+    offB[ks] = lds0 + BM * BKB + (wn * WTN + l31) * BKB + coff;
+  }
+
+  int cur = 0, nxt = S - 1;                   // stage of tile kt, stage of tile kt + S - 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;            // tiles issued after kt and still allowed in flight
+    if (ahead >= S - 2) wait_vmcnt<(S - 2) * IPT>();
+    else if (S > 3 && ahead == 1) wait_vmcnt<IPT>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int c = tid; c < 2 * BN; c += 256) {
-      const int which = c / BN, col = c - which * BN;
-      if (n0 + col < p.N) {
-        const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
-                        red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
-        p.stats[((size_t)mt * 2 + which) * p.N + n0 + col] = s;
-      }
-    }
+    if (issued < nk) issue_next(nxt);
+    const uint32_t sbase = cur * STAGE;
+    ring_tile_mma<T, NI, MI, KS, BKB>(acc, offA, offB, sbase);
+    cur = cur + 1 == S ? 0 : cur + 1;
+    nxt = nxt + 1 == S ? 0 : nxt + 1;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();      // every wave is done reading the ring before the epilogue reuses it
+  asm volatile("" ::: "memory");
+
+  igemm_epilogue<TOut, BM, BN>(p, acc, smem, m0, n0, mt);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, bool ALIGNED>
+template <typename T, typename TOut, int BM, int BN, int BKB, int S, int MINB>
+void launch_glds(const IgemmParams& p, hipStream_t stream) {
+  constexpr int ring_bytes = S * (BM + BN) * BKB;
+  constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
+  constexpr int red_bytes = 4 * 2 * BN * 4;
+  constexpr int lds = ring_bytes > epi_bytes ? (ring_bytes > red_bytes ? ring_bytes : red_bytes)
+                                             : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
+  auto kern = igemm_glds_kernel<T, TOut, BM, BN, BKB, S, MINB>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+}
+
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED>
 void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + BN) * LDR;
@@ -354,7 +599,7 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   int lds = (nk > 1 ? 2 : 1) * stage_bytes;
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, ALIGNED>;
+  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -362,35 +607,79 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
     attr_done = true;
   }
   const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  if (getenv("DPA_DEBUG")) { fprintf(stderr, "  launch tiles=%ld lds=%d nk=%d\n", tiles, lds, nk); fflush(stderr); }
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
-  if (getenv("DPA_DEBUG")) { fprintf(stderr, "  launched\n"); fflush(stderr); }
+}
+
+// Tile configurations.  0..3 exist for every dtype pair; further experimental ones can be appended for
+// 16-bit in == out (the training hot path) and timed per layer with `bench/conv_layers.py --sweep`
+// (igemm_force_config); profiles/r1_igemm_sweep.md holds the sweep the heuristic below came from.
+struct TileCfg { int bm, bn, bkb, minb; };
+constexpr TileCfg kCfgs[] = {
+    {128, 128, 128, 2}, {128, 64, 128, 2}, {128, 128, 64, 2}, {128, 64, 64, 2},   // 0..3 (all dtypes)
+    // LDS-DMA ring kernels (16-bit in == out): 4: 64B x3  5: 64B x4  6: 128B x3  7: narrow 64B x4
+    // 8: 128B x2  9: narrow 128B x3
+    {128, 128, 64, 3}, {128, 128, 64, 2}, {128, 128, 128, 1}, {128, 64, 64, 3},
+    {128, 128, 128, 2}, {128, 64, 128, 2},
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kNumRegCfgs = 4;     // 0..3 register-staged; the rest are LDS-DMA ring kernels (tap table in lanes)
+
+int g_force_cfg = -1;
+
+// Pure function of the problem: the stats slab allocation (igemm_stats_rows) must agree with the launch.
+// Measured (MI355X, batch 256 ResNet-50 shapes): 64-byte K tiles (40 KB LDS, 3-4 blocks/CU) win whenever
+// there are enough tiles to fill the chip more than twice and the reduction is short -- those layers are
+// bound by bytes in flight per CU; 128-byte K tiles (half the barriers) win for long reductions and for
+// launches of <= 2 tiles per CU.
+int choose_cfg(int M, int N, int Cred, int ntaps, int esize, bool ext) {
+  const bool k128 = Cred % (128 / esize) == 0;
+  if (g_force_cfg >= 0 && ext && g_force_cfg < kNumCfgs) {
+    const TileCfg c = kCfgs[g_force_cfg];
+    if (Cred % (c.bkb / esize) == 0 && (g_force_cfg < kNumRegCfgs || ntaps <= 64)) return g_force_cfg;
+  }
+  const bool wide = N > 64;
+  const long tiles = (long)ceil_div(M, 128) * ceil_div(N, wide ? 128 : 64);
+  const long kbytes = (long)ntaps * Cred * esize;
+  const bool deep = k128 && (kbytes >= 4096 || tiles <= 512);
+  if (deep) return wide ? 0 : 1;
+  return wide ? 2 : 3;   // also the non-aligned gather (64-byte K tiles)
 }
 
 template <typename T, typename TOut>
 void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
-  constexpr int BK64 = 64 / (int)sizeof(T), BK128 = 128 / (int)sizeof(T);
-  const bool wide = p.N > 64;
-  if (p.Cred % BK128 == 0) {
-    if (wide) launch_cfg<T, TOut, 128, 128, 128, true>(p, stream);
-    else launch_cfg<T, TOut, 128, 64, 128, true>(p, stream);
-  } else if (p.Cred % BK64 == 0) {
-    if (wide) launch_cfg<T, TOut, 128, 128, 64, true>(p, stream);
-    else launch_cfg<T, TOut, 128, 64, 64, true>(p, stream);
-  } else {
-    if (wide) launch_cfg<T, TOut, 128, 128, 64, false>(p, stream);
-    else launch_cfg<T, TOut, 128, 64, 64, false>(p, stream);
+  constexpr int ES = (int)sizeof(T);
+  constexpr bool EXT = sizeof(T) == 2 && std::is_same<T, TOut>::value;   // tuning hook applies here only
+  const bool aligned = p.Cred % (64 / ES) == 0;
+  const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
+  if (!aligned) {
+    if (cfg == 2) launch_cfg<T, TOut, 128, 128, 64, 2, false>(p, stream);
+    else launch_cfg<T, TOut, 128, 64, 64, 2, false>(p, stream);
+    return;
   }
+  switch (cfg) {
+    case 0: launch_cfg<T, TOut, 128, 128, 128, 2, true>(p, stream); return;
+    case 1: launch_cfg<T, TOut, 128, 64, 128, 2, true>(p, stream); return;
+    case 2: launch_cfg<T, TOut, 128, 128, 64, 2, true>(p, stream); return;
+    case 3: launch_cfg<T, TOut, 128, 64, 64, 2, true>(p, stream); return;
+    default: break;
+  }
+  if constexpr (EXT) {
+    switch (cfg) {
+      case 4: launch_glds<T, TOut, 128, 128, 64, 3, 3>(p, stream); return;
+      case 5: launch_glds<T, TOut, 128, 128, 64, 4, 2>(p, stream); return;
+      case 6: launch_glds<T, TOut, 128, 128, 128, 3, 1>(p, stream); return;
+      case 7: launch_glds<T, TOut, 128, 64, 64, 4, 3>(p, stream); return;
+      case 8: launch_glds<T, TOut, 128, 128, 128, 2, 2>(p, stream); return;
+      case 9: launch_glds<T, TOut, 128, 64, 128, 3, 2>(p, stream); return;
+      default: break;
+    }
+  }
+  throw std::logic_error("igemm: bad tile configuration");
 }
 
 }  // namespace
 
 void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream) {
-  if (getenv("DPA_DEBUG")) {
-    fprintf(stderr, "igemm M=%d N=%d Cred=%d ntaps=%d lda=%d ldb=%d ldc=%d IH=%d IW=%d S=%d,%d flags=%d dt=%d/%d\n", p.M, p.N,
-            p.Cred, p.ntaps, p.lda, p.ldb, p.ldc, p.IH, p.IW, p.SY, p.SX, p.flags, dtype, out_dtype);
-    fflush(stderr);
-  }
   const int vec = dtype == kF32 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0) return;
   if (p.Cred % vec != 0 || p.lda % vec != 0 || p.ldb % vec != 0)
@@ -408,6 +697,15 @@ void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   else throw std::invalid_argument("igemm: unsupported dtype combination");
   DPA_CHECK_HIP(hipGetLastError());
 }
+
+int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype) {
+  const int es = dtype == kF32 ? 4 : 2;
+  const int cfg = choose_cfg(M, N, Cred, ntaps, es, es == 2 && dtype == out_dtype);
+  return ceil_div(M, kCfgs[cfg].bm);
+}
+
+void igemm_force_config(int cfg) { g_force_cfg = cfg; }
+int igemm_num_configs() { return kNumCfgs; }
 
 int igemm_tile_m(int /*dtype*/) { return 128; }
 

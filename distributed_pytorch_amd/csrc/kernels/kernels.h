@@ -26,6 +26,11 @@ struct IgemmParams {
 };
 void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
 int igemm_tile_m(int dtype);
+// rows of the per-tile BatchNorm statistics slab the launch for this problem will write
+int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype);
+// tuning hook: force tile configuration `cfg` (16-bit in == out problems), -1 = automatic
+void igemm_force_config(int cfg);
+int igemm_num_configs();
 
 // ------------------------------------------------------------------------------ wgrad.hip
 struct WgradParams {
@@ -44,6 +49,9 @@ void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);
 void slab_reduce_launch(const float* slab, int splits, long n, void* out, int out_dtype, float beta,
                         hipStream_t stream);
 int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split);
+void wgrad_force_config(int cfg);   // tuning hook, -1 = automatic
+int wgrad_num_configs();
+void wgrad_set_target_blocks(int n);   // tuning hook: workgroups the pixel split aims for
 
 // ------------------------------------------------------------------------------ bn.hip
 // x, y, residual, dy, dx: [M][C] (NHWC flattened), stats fp32.

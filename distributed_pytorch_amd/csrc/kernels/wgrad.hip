@@ -31,10 +31,10 @@ __device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
   return r;
 }
 
-template <typename T, int BI, int BJ>
+template <typename T, int BI, int BJ, int KB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int BKP = 64 / (int)sizeof(T);             // pixels per K tile (64 bytes of K per column)
+  constexpr int BKP = KB / (int)sizeof(T);             // pixels per K tile (KB bytes of K per column)
   constexpr int LDP = BI * (int)sizeof(T) + 64;        // row stride = 64 (mod 128): conflict-free tr reads
   constexpr int LDQ = BJ * (int)sizeof(T) + 64;
   constexpr int CPP = BI * (int)sizeof(T) / 16, CPQ = BJ * (int)sizeof(T) / 16;
@@ -263,28 +263,66 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-template <typename T, int BI, int BJ>
+template <typename T, int BI, int BJ, int KB>
 void launch_cfg(const WgradParams& p, hipStream_t stream) {
-  constexpr int BKP = 64 / (int)sizeof(T);
+  constexpr int BKP = KB / (int)sizeof(T);
   constexpr int lds = 2 * BKP * ((BI + BJ) * (int)sizeof(T) + 128);
+  auto kern = wgrad_kernel<T, BI, BJ, KB>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
   const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
-  hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+}
+
+// Tile configurations (output channels x im2col columns x bytes of pixels per K tile); picked per
+// problem shape from measurements (bench/conv_layers.py --sweep-wgrad; wgrad_force_config).
+struct WCfg { int bi, bj, kb; };
+constexpr WCfg kWCfgs[] = {
+    {128, 128, 64}, {64, 64, 64}, {64, 256, 64}, {64, 128, 64}, {128, 64, 64},
+};
+constexpr int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
+int g_force_wcfg = -1;
+int g_target_blocks = 768;
+
+// From the per-layer sweep (profiles/r1_wgrad_sweep.md): square 128x128 tiles everywhere except the
+// 64-channel layers, where a tile as wide as the short side allows avoids re-reading the long operand.
+// 128-byte K tiles and 256-wide output tiles never won.
+int choose_wcfg(long M, int N, int Ktot) {
+  (void)M;
+  if (g_force_wcfg >= 0 && g_force_wcfg < kNumWCfgs) return g_force_wcfg;
+  if (N <= 64) return Ktot <= 64 ? 1 : (Ktot <= 256 ? 3 : 2);
+  if (Ktot <= 64) return 4;
+  return 0;
 }
 
 template <typename T>
 void dispatch(const WgradParams& p, hipStream_t stream) {
-  if (p.N > 64 && p.Ktot > 64) launch_cfg<T, 128, 128>(p, stream);
-  else launch_cfg<T, 64, 64>(p, stream);
+  switch (choose_wcfg(p.M, p.N, p.Ktot)) {
+    case 0: launch_cfg<T, 128, 128, 64>(p, stream); return;
+    case 1: launch_cfg<T, 64, 64, 64>(p, stream); return;
+    case 2: launch_cfg<T, 64, 256, 64>(p, stream); return;
+    case 3: launch_cfg<T, 64, 128, 64>(p, stream); return;
+    case 4: launch_cfg<T, 128, 64, 64>(p, stream); return;
+    default: throw std::logic_error("wgrad: bad tile configuration");
+  }
 }
 
 }  // namespace
 
+void wgrad_force_config(int cfg) { g_force_wcfg = cfg; }
+void wgrad_set_target_blocks(int n) { g_target_blocks = n > 0 ? n : 768; }
+int wgrad_num_configs() { return kNumWCfgs; }
+
 int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split) {
-  const int bkp = dtype == kF32 ? 16 : 32;
-  const int tile = (N > 64 && Ktot > 64) ? 128 : 64;
-  const long tiles = (long)ceil_div(N, tile) * ceil_div(Ktot, tile);
+  const WCfg c = kWCfgs[choose_wcfg(M, N, Ktot)];
+  const int bkp = c.kb / (dtype == kF32 ? 4 : 2);
+  const long tiles = (long)ceil_div(N, c.bi) * ceil_div(Ktot, c.bj);
   // aim for ~3 workgroups per CU, keep >= 8 K tiles per workgroup, and bound the slab size
-  long splits = (768 + tiles - 1) / tiles;
+  long splits = (g_target_blocks + tiles - 1) / tiles;
   const long max_by_work = (M + 8l * bkp - 1) / (8l * bkp);
   if (splits > max_by_work) splits = max_by_work;
   const long out_elems = (long)N * Ktot;
@@ -305,6 +343,11 @@ void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
     throw std::invalid_argument("wgrad: channel counts / strides must be multiples of 16 bytes");
   if (p.Ktot != p.ntaps * p.Cred) throw std::invalid_argument("wgrad: Ktot != ntaps*Cred");
   if ((long)p.splits * p.pix_per_split < p.M) throw std::invalid_argument("wgrad: splits do not cover M");
+  {
+    const int bkp = kWCfgs[choose_wcfg(p.M, p.N, p.Ktot)].kb / (dtype == kF32 ? 4 : 2);
+    if (p.splits > 1 && p.pix_per_split % bkp != 0)
+      throw std::invalid_argument("wgrad: pix_per_split must be a multiple of the K tile");
+  }
   if (dtype == kF32) dispatch<float>(p, stream);
   else if (dtype == kBF16) dispatch<bf16_t>(p, stream);
   else if (dtype == kF16) dispatch<f16_t>(p, stream);

@@ -280,7 +280,7 @@ class _ConvFn(torch.autograd.Function):
         M = NB * OH * OW
         stats = None
         if want_stats:
-            tiles = (M + C().igemm_tile_m(_dt(x)) - 1) // C().igemm_tile_m(_dt(x))
+            tiles = C().igemm_stats_rows(M, K, Cx, R * S, _dt(x), _dt(x))
             stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
         taps = _tap_table(x.device, _fprop_taps(R, S, ph, pw))
         bias_f = None

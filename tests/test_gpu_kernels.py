@@ -83,6 +83,38 @@ def test_conv_fwd_bwd(case, dtype, bias_relu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_every_tile_config(dtype):
+    """Every tile configuration of the tuning tables (igemm_force_config / wgrad_force_config) is exact."""
+    from distributed_pytorch_amd.ops import hip_ops
+    C = hip_ops.C()
+    torch.manual_seed(3)
+    N, H, Cin, Cout, k, s, p = 3, 13, 128, 192, 3, 1, 1
+    x = torch.randn(N, H, H, Cin, device=DEV).to(dtype)
+    w = (torch.randn(Cout, Cin, k, k, device=DEV) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, H, H, Cout, device=DEV).to(dtype)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.to(dtype).float().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, s, p)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    try:
+        for cfg in range(C.igemm_num_configs()):
+            C.igemm_force_config(cfg)
+            y, stats = hip_ops.conv2d(x, w, None, (s, s), (p, p), False, None, True, False)
+            _close(y.permute(0, 3, 1, 2), yr, dtype, what="fprop cfg %d" % cfg)
+            _close(stats.sum(0)[0], y.float().reshape(-1, Cout).sum(0), torch.float32, scale=10, what="stats cfg %d" % cfg)
+            dx = hip_ops.conv_dgrad(gy, w, tuple(x.shape), (s, s), (p, p))
+            _close(dx.permute(0, 3, 1, 2), xr.grad, dtype, what="dgrad cfg %d" % cfg)
+        C.igemm_force_config(-1)
+        for cfg in range(C.wgrad_num_configs()):
+            C.wgrad_force_config(cfg)
+            dw = hip_ops.conv_wgrad(gy, x, w, (s, s), (p, p))
+            _close(dw, wr.grad, dtype, what="wgrad cfg %d" % cfg)
+    finally:
+        C.igemm_force_config(-1)
+        C.wgrad_force_config(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_stats_epilogue(dtype):
     torch.manual_seed(1)
     x = torch.randn(6, 14, 14, 64, device=DEV).to(dtype)
