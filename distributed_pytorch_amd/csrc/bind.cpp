@@ -217,4 +217,5 @@ PYBIND11_MODULE(_C, m) {
   });
 
   bind_comm(m);
+  bind_store(m);
 }

@@ -18,12 +18,12 @@ class DistributedSampler:
                  rank: Optional[int] = None, shuffle: bool = True, seed: int = 0,
                  drop_last: bool = False):
         if num_replicas is None or rank is None:
-            import torch.distributed as dist
+            from ..parallel import process_group as pg
 
-            if not (dist.is_available() and dist.is_initialized()):
+            if not pg.is_initialized():
                 raise RuntimeError("DistributedSampler needs num_replicas/rank or an initialised group")
-            num_replicas = dist.get_world_size() if num_replicas is None else num_replicas
-            rank = dist.get_rank() if rank is None else rank
+            num_replicas = pg.get_world_size() if num_replicas is None else num_replicas
+            rank = pg.get_rank() if rank is None else rank
         if not 0 <= rank < num_replicas:
             raise ValueError("invalid rank {} for {} replicas".format(rank, num_replicas))
         self.n = dataset_or_len if isinstance(dataset_or_len, int) else len(dataset_or_len)

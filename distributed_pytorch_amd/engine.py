@@ -27,7 +27,7 @@ import warnings
 from typing import Optional
 
 import torch
-import torch.distributed as dist
+from .parallel import process_group as pg
 
 from . import amp, checkpoint as ckpt, launch, models, schedule
 from .data.datasets import ImageFolder, SyntheticImageNet, fast_collate
@@ -201,7 +201,7 @@ def main_worker(local_rank: int, ngpus_per_node: int, args) -> None:
                                  legacy_prec1_key=(script == "apex"), extra=extra),
                 is_best, out_dir=log_dir)
         if args.distributed:
-            dist.barrier()          # nobody races ahead of the checkpoint file (SURVEY.md C-l)
+            pg.barrier()            # nobody races ahead of the checkpoint file (SURVEY.md C-l)
         if writer is not None:
             for tag, v in (("Throughput/train", tr["throughput"]), ("Throughput/val", va["throughput"]),
                            ("Time/train", tr["batch_time"]), ("Time/val", va["batch_time"]),
@@ -217,7 +217,7 @@ def main_worker(local_rank: int, ngpus_per_node: int, args) -> None:
                     ckpt.build_state(epoch, args.arch, model, optimizer, best_acc1, args.distributed,
                                      extra={"training_time": training_time}), is_best, out_dir=log_dir)
             if args.distributed:
-                dist.barrier()
+                pg.barrier()
             print("Training time: {:.3f} s; desired accuracy {:.3f} reached at epoch {}".format(
                 training_time, desired, epoch + 1))
             break
@@ -284,7 +284,7 @@ class _Run:
         """APX averages metrics over ranks (``reduce_tensor``), nd/ddp report rank-local values."""
         if self.script == "apex" and self.args.distributed:
             packed = packed.clone()
-            dist.all_reduce(packed)         # sums of (loss*n, correct, n): one collective, exact mean
+            pg.all_reduce_sum(packed)       # sums of (loss*n, correct, n): one collective, exact mean
         return packed
 
     def _log(self, rec: dict) -> None:

@@ -14,7 +14,6 @@ affinity per local rank, and a ``--fault-inject RANK:STEP`` hook for tests.
 """
 from __future__ import annotations
 
-import datetime
 import multiprocessing as mp
 import os
 import signal
@@ -24,7 +23,6 @@ import traceback
 from typing import Callable, Optional, Tuple
 
 import torch
-import torch.distributed as dist
 
 
 def device_count() -> int:
@@ -75,23 +73,16 @@ def set_affinity(local_rank: int, nprocs: int) -> None:
 
 def init_process_group(backend: str, init_method: str, world_size: int, rank: int,
                        timeout_s: float = 600.0, use_gpu: bool = True) -> None:
-    backend = resolve_backend(backend, use_gpu)
-    kwargs = dict(backend=backend, init_method=init_method, world_size=world_size, rank=rank,
-                  timeout=datetime.timedelta(seconds=timeout_s))
-    if backend == "nccl" and use_gpu:
-        try:
-            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
-        except Exception:  # noqa: BLE001
-            pass
-    dist.init_process_group(**kwargs)
+    """``--dist-backend nccl|rccl|gloo`` -> torch.distributed; ``native`` -> TcpStore + C++ RCCL communicator."""
+    from .parallel import process_group as pg
+
+    pg.init_process_group(backend, init_method, world_size, rank, timeout_s=timeout_s, use_gpu=use_gpu)
 
 
 def shutdown() -> None:
-    if dist.is_available() and dist.is_initialized():
-        try:
-            dist.destroy_process_group()
-        except Exception:  # noqa: BLE001
-            pass
+    from .parallel import process_group as pg
+
+    pg.destroy_process_group()
 
 
 # ----------------------------------------------------------------------------- supervisor

@@ -431,20 +431,20 @@ _FORCE_SYNC_PATH = False     # tests: take the SyncBN code path (all-reduce of a
 
 
 def _group_size(group) -> int:
-    import torch.distributed as dist
+    from ..parallel import process_group as pg
 
     if _FORCE_SYNC_PATH and group is not None:
         return 2
-    if group is None or not (dist.is_available() and dist.is_initialized()):
+    if group is None or not pg.is_initialized():
         return 1
-    return dist.get_world_size(None if group == "world" else group)
+    return pg.get_world_size(None if group == "world" else group)
 
 
 def _all_reduce_sum(t: torch.Tensor, group) -> None:
-    import torch.distributed as dist
+    from ..parallel import process_group as pg
 
-    if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(t, group=None if group == "world" else group)
+    if pg.is_initialized():
+        pg.all_reduce_sum(t, group=None if group == "world" else group)
 
 
 class _BNFn(torch.autograd.Function):

@@ -65,6 +65,11 @@ class TorchComm:
 def default_comm(kind: str = "auto", group=None):
     """``auto``: native RCCL communicator when built and the tensors live on a GPU
     process group; ``torch.distributed`` otherwise."""
+    from . import process_group as pg
+
+    npg = pg.native()
+    if npg is not None:                       # native process group: its communicators, nothing to negotiate
+        return npg.gpu_comm if npg.gpu_comm is not None else npg.host_comm
     if kind in ("auto", "native"):
         try:
             from .native_comm import NativeComm
@@ -84,9 +89,10 @@ def default_comm(kind: str = "auto", group=None):
 def reduce_tensor(t: torch.Tensor, world_size: Optional[int] = None) -> torch.Tensor:
     """Mean over ranks of a small metric tensor (reference ``reduce_tensor``,
     ``imagenet_ddp_apex.py:562-566``).  Callers pack loss/top1/top5 into ONE tensor."""
-    if not (dist.is_available() and dist.is_initialized()):
+    from . import process_group as pg
+
+    if not pg.is_initialized():
         return t.clone()
-    rt = t.clone()
-    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
-    rt /= (world_size or dist.get_world_size())
+    rt = pg.all_reduce_sum(t.clone())
+    rt /= (world_size or pg.get_world_size())
     return rt

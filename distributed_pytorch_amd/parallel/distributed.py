@@ -34,7 +34,7 @@ import contextlib
 from typing import Dict, List, Optional
 
 import torch
-import torch.distributed as dist
+from . import process_group as pg
 from torch import nn
 
 from ..ops import grad_sink
@@ -241,12 +241,12 @@ class DistributedDataParallel(nn.Module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.device = self.params[0].device
         self.on_gpu = self.device.type == "cuda"
-        if dist.is_available() and dist.is_initialized():
+        if pg.is_initialized():
             self.comm = default_comm(comm, process_group)
         else:
             self.comm = None
         self.world_size = self.comm.world_size if self.comm is not None else 1
-        self.native = self.comm is not None and not isinstance(self.comm, TorchComm)
+        self.native = self.comm is not None and hasattr(self.comm, "make_reducer")   # C++ RCCL communicator
         self.comm_stream = torch.cuda.Stream(self.device) \
             if self.on_gpu and not self.native else None
 

@@ -17,7 +17,7 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
-import torch.distributed as dist
+from . import process_group as pg
 from torch import nn
 
 from ..nn.modules import BatchNorm2d, SyncBatchNorm
@@ -28,14 +28,14 @@ def _group(group):
 
 
 def _world(group) -> int:
-    if not (dist.is_available() and dist.is_initialized()):
+    if not pg.is_initialized():
         return 1
-    return dist.get_world_size(_group(group))
+    return pg.get_world_size(_group(group))
 
 
 def all_reduce_sum_(t: torch.Tensor, group) -> torch.Tensor:
     if _world(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group(group))
+        pg.all_reduce_sum(t, group=_group(group))
     return t
 
 

@@ -10,10 +10,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo"):
     from distributed_pytorch_amd import launch
 
-    launch.init_process_group("gloo", "tcp://127.0.0.1:%d" % port, world, rank, timeout_s=60, use_gpu=False)
+    launch.init_process_group(backend, "tcp://127.0.0.1:%d" % port, world, rank, timeout_s=60, use_gpu=False)
+
+
+def _finish():
+    from distributed_pytorch_amd.parallel import process_group as pg
+
+    pg.barrier()
+    pg.destroy_process_group()
 
 
 def _model(num_classes=10):
@@ -23,13 +30,13 @@ def _model(num_classes=10):
     return models.create_model("resnet18", num_classes=num_classes)
 
 
-def ddp_grads(local_rank, world, port, out_dir, delay):
+def ddp_grads(local_rank, world, port, out_dir, delay, backend="gloo"):
     """Each rank: its shard of a fixed global batch -> save averaged grads + params after one step."""
     from distributed_pytorch_amd.optim import FusedSGD
     from distributed_pytorch_amd.ops import functional as F
     from distributed_pytorch_amd.parallel import DistributedDataParallel
 
-    _init(local_rank, world, port)
+    _init(local_rank, world, port, backend)
     model = _model()
     if local_rank != 0:                     # DDP must broadcast rank 0's weights
         with torch.no_grad():
@@ -53,15 +60,14 @@ def ddp_grads(local_rank, world, port, out_dir, delay):
     torch.save({"grads": grads, "params": {n: p.detach().clone() for n, p in ddp.named_parameters()},
                 "buckets": ddp.bucket_summary(), "keys": list(ddp.state_dict().keys())[:3]},
                os.path.join(out_dir, "rank%d.pt" % local_rank))
-    dist.barrier()
-    dist.destroy_process_group()
+    _finish()
 
 
-def syncbn_stats(local_rank, world, port, out_dir):
+def syncbn_stats(local_rank, world, port, out_dir, backend="gloo"):
     from distributed_pytorch_amd.nn.modules import BatchNorm2d
     from distributed_pytorch_amd.parallel import convert_syncbn_model
 
-    _init(local_rank, world, port)
+    _init(local_rank, world, port, backend)
     torch.manual_seed(7)
     x = torch.randn(8, 5, 5, 16)
     bn = convert_syncbn_model(torch.nn.Sequential(BatchNorm2d(16)))[0]
@@ -71,8 +77,7 @@ def syncbn_stats(local_rank, world, port, out_dir):
     (y * torch.arange(16.0)).sum().backward()
     torch.save({"y": y.detach(), "dx": xs.grad, "rm": bn.running_mean.clone(), "rv": bn.running_var.clone(),
                 "dw": bn.weight.grad.clone()}, os.path.join(out_dir, "rank%d.pt" % local_rank))
-    dist.barrier()
-    dist.destroy_process_group()
+    _finish()
 
 
 def crash_one(local_rank, world, port):
@@ -87,3 +92,32 @@ def crash_one(local_rank, world, port):
     import time
 
     time.sleep(120)
+
+
+def store_ops(local_rank, world, port, out_dir):
+    """TcpStore semantics across processes: blocking get, counters, barrier, host collectives."""
+    from distributed_pytorch_amd.parallel import process_group as pg
+
+    _init(local_rank, world, port, "native")
+    npg = pg.native()
+    st = npg.store
+    if local_rank == 1:
+        import time
+
+        time.sleep(0.3)
+        st.set("from1", b"payload")
+    got = st.get("from1")                              # rank 0 blocks until rank 1 publishes
+    n = st.add("counter", local_rank + 1)
+    pg.barrier()
+    total = st.add("counter", 0)
+    t = torch.arange(6, dtype=torch.float32) * (local_rank + 1)
+    pg.all_reduce_sum(t)
+    b = torch.full((3,), float(local_rank))
+    pg.broadcast(b, src=1)
+    obj = npg.broadcast_object({"rank": local_rank} if local_rank == 0 else None, src=0)
+    gathered = torch.empty(world, 2)
+    npg.host_comm.all_gather(gathered, torch.tensor([float(local_rank), 10.0 + local_rank]))
+    torch.save({"got": got, "n": n, "total": total, "sum": t, "bcast": b, "obj": obj, "gathered": gathered,
+                "rank": pg.get_rank(), "world": pg.get_world_size(), "backend": pg.get_backend()},
+               os.path.join(out_dir, "rank%d.pt" % local_rank))
+    _finish()

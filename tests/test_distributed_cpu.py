@@ -36,10 +36,24 @@ def test_bucket_planner_caps_order_and_alignment():
     assert chunk_ranges(10, 4, 16) == [(0, 4), (4, 8), (8, 10)]
 
 
-@pytest.mark.parametrize("delay", [False, True])
-def test_ddp_matches_single_process_on_full_batch(tmp_path, delay):
+def test_native_store_rendezvous_and_host_collectives(tmp_path):
+    """--dist-backend native: C++ TcpStore rendezvous, no torch.distributed anywhere."""
     world = 2
-    launch.spawn(W.ddp_grads, world, (world, _port(), str(tmp_path), delay))
+    launch.spawn(W.store_ops, world, (world, _port(), str(tmp_path)))
+    rs = [torch.load(tmp_path / ("rank%d.pt" % r), weights_only=True) for r in range(world)]
+    for r, d in enumerate(rs):
+        assert d["got"] == b"payload" and d["total"] == 3 and d["rank"] == r and d["world"] == 2
+        assert d["backend"] == "native" and d["obj"] == {"rank": 0}
+        assert torch.equal(d["sum"], torch.arange(6, dtype=torch.float32) * 3)
+        assert torch.equal(d["bcast"], torch.ones(3))
+        assert torch.equal(d["gathered"], torch.tensor([[0.0, 10.0], [1.0, 11.0]]))
+    assert sorted(d["n"] for d in rs) in ([1, 3], [2, 3])
+
+
+@pytest.mark.parametrize("delay,backend", [(False, "gloo"), (True, "gloo"), (False, "native")])
+def test_ddp_matches_single_process_on_full_batch(tmp_path, delay, backend):
+    world = 2
+    launch.spawn(W.ddp_grads, world, (world, _port(), str(tmp_path), delay, backend))
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
     for n in r0["grads"]:
@@ -66,9 +80,10 @@ def test_ddp_matches_single_process_on_full_batch(tmp_path, delay):
         assert torch.allclose(got, p.grad, rtol=1e-3, atol=1e-5), (n, (got - p.grad).abs().max())
 
 
-def test_syncbn_equals_batchnorm_over_the_global_batch(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "native"])
+def test_syncbn_equals_batchnorm_over_the_global_batch(tmp_path, backend):
     world = 2
-    launch.spawn(W.syncbn_stats, world, (world, _port(), str(tmp_path)))
+    launch.spawn(W.syncbn_stats, world, (world, _port(), str(tmp_path), backend))
     rs = [torch.load(tmp_path / ("rank%d.pt" % r), weights_only=True) for r in range(world)]
     torch.manual_seed(7)
     x = torch.randn(8, 5, 5, 16).requires_grad_(True)
@@ -112,10 +127,11 @@ def test_nd_trainer_cpu_trains_checkpoints_and_resumes(tmp_path):
     assert r3.returncode == 0 and "Epoch:" not in r3.stdout and "Test:" in r3.stdout
 
 
-def test_ddp_trainer_two_gloo_ranks_and_desired_acc_stop(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "native"])
+def test_ddp_trainer_two_ranks_and_desired_acc_stop(tmp_path, backend):
     r = _run("imagenet_ddp.py", "--synthetic", "-a", "resnet18", "-b", "16", "-p", "1", "--cpu", "--steps", "2",
              "--synthetic-size", "64", "--synthetic-val-size", "16", "--num-classes", "10", "--epochs", "3",
-             "--dist-url", "tcp://127.0.0.1:%d" % _port(), "--dist-backend", "gloo", "--world-size", "1",
+             "--dist-url", "tcp://127.0.0.1:%d" % _port(), "--dist-backend", backend, "--world-size", "1",
              "--rank", "0", "--desired-acc", "0.0", "--out-dir", str(tmp_path), env={"DPA_NPROC_PER_NODE": "2"})
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.count("=> creating model 'resnet18'") == 2                # one process per "GPU"

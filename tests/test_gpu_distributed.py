@@ -88,3 +88,44 @@ def test_native_comm_and_cpp_reducer_world1():
     finally:
         os.environ.pop("DPA_FORCE_NATIVE_REDUCER", None)
         dist.destroy_process_group()
+
+
+def test_native_process_group_bootstraps_rccl_through_tcpstore():
+    """--dist-backend native: TcpStore rendezvous -> ncclUniqueId -> C++ communicator, no torch.distributed."""
+    import socket
+
+    import torch.distributed as dist
+
+    from distributed_pytorch_amd import amp, launch, models
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+    from distributed_pytorch_amd.parallel import process_group as pg
+    from distributed_pytorch_amd.parallel.comm import reduce_tensor
+    from distributed_pytorch_amd.parallel.native_comm import NativeComm
+
+    amp.state().reset()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["DPA_FORCE_NATIVE_REDUCER"] = "1"
+    launch.init_process_group("native", "tcp://127.0.0.1:%d" % port, 1, 0, timeout_s=60, use_gpu=True)
+    try:
+        assert not dist.is_initialized() and pg.is_initialized() and pg.get_backend() == "native"
+        assert isinstance(pg.native().gpu_comm, NativeComm)
+        torch.manual_seed(0)
+        model = models.create_model("resnet18", num_classes=10).cuda().train()
+        ddp = DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=8.0, first_bucket_mb=1.0)
+        assert ddp.comm is pg.native().gpu_comm and type(ddp.reducer).__name__ == "_NativeReducer"
+        opt = FusedSGD(ddp.parameters(), lr=0.05, momentum=0.9)
+        x = torch.randint(0, 256, (16, 64, 64, 3), dtype=torch.uint8, device="cuda")
+        t = torch.randint(0, 10, (16,), device="cuda")
+        losses = [_step(ddp, opt, x, t) for _ in range(6)]
+        assert losses[-1] < losses[0], losses
+        m = reduce_tensor(torch.tensor([1.0, 2.0, 3.0], device="cuda"))
+        cpu = pg.all_reduce_sum(torch.tensor([4.0]))            # host tensors go through the store
+        pg.barrier()
+        assert m.tolist() == [1.0, 2.0, 3.0] and cpu.item() == 4.0
+    finally:
+        os.environ.pop("DPA_FORCE_NATIVE_REDUCER", None)
+        pg.destroy_process_group()
