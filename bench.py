@@ -88,8 +88,16 @@ def main():
     pre = StreamPrefetcher(data, device, dtype=amp.compute_dtype(torch.float32),
                            pad_c=0 if F._TORCH_BASELINE else 8)
 
+    graphed = None
+    if args.graph and world == 1 and not F._TORCH_BASELINE:
+        from distributed_pytorch_amd.utils.graph import GraphedTrainStep
+
+        graphed = GraphedTrainStep(model, opt, warmup=2)
+
     def step():
         images, target = pre.next()
+        if graphed is not None:
+            return graphed(images, target)[0]
         out = model(images)
         loss, rec = F.loss_and_metrics(out, target)
         opt.zero_grad()
@@ -131,7 +139,8 @@ def main():
             "config": {"model": args.arch, "global_batch": args.batch_size * world,
                        "per_gpu_batch": args.batch_size, "seq_len": None, "image_size": args.image_size,
                        "parallelism": "dp%d" % world, "optimizer": "sgd+momentum+wd (fused)",
-                       "amp": "O2 " + args.dtype if args.dtype != "fp32" else "O0"},
+                       "amp": "O2 " + args.dtype if args.dtype != "fp32" else "O0",
+                       "hip_graph": bool(graphed is not None and graphed.replays > 0)},
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()

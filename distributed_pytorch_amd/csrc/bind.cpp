@@ -183,8 +183,9 @@ PYBIND11_MODULE(_C, m) {
     add_relu_fwd_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(y), n, dtype, st(s));
   });
   m.def("dropout_fwd", [](uintptr_t x, uintptr_t y, uintptr_t mask, long n, float p, uint64_t seed, uint64_t offset,
-                          int dtype, uintptr_t s) {
-    dropout_fwd_launch(ptr<const void>(x), ptr<void>(y), ptr<uint8_t>(mask), n, p, seed, offset, dtype, st(s));
+                          uintptr_t counter, int dtype, uintptr_t s) {
+    dropout_fwd_launch(ptr<const void>(x), ptr<void>(y), ptr<uint8_t>(mask), n, p, seed, offset,
+                       ptr<uint64_t>(counter), dtype, st(s));
   });
   m.def("dropout_bwd", [](uintptr_t dy, uintptr_t mask, uintptr_t dx, long n, float p, int dtype, uintptr_t s) {
     dropout_bwd_launch(ptr<const void>(dy), ptr<const uint8_t>(mask), ptr<void>(dx), n, p, dtype, st(s));

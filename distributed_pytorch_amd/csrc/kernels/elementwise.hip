@@ -112,7 +112,9 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           uint8_t* __restrict__ mask, long n, float p, uint64_t seed,
-                                                          uint64_t offset) {
+                                                          uint64_t offset, const uint64_t* __restrict__ counter) {
+  // the stream position may live on the device (counter) so a captured hipGraph draws fresh masks per replay
+  if (counter != nullptr) offset += *counter;
   const float scale = 1.f / (1.f - p);
   const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
   const long stride = (long)gridDim.x * blockDim.x;
@@ -121,6 +123,9 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ 
     mask[i] = keep ? 1 : 0;
     y[i] = from_float<T>(keep ? to_float(x[i]) * scale : 0.f);
   }
+}
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter += n;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask,
@@ -206,10 +211,12 @@ void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtyp
 }
 
 void dropout_fwd_launch(const void* x, void* y, uint8_t* mask, long n, float p, uint64_t seed, uint64_t offset,
-                        int dtype, hipStream_t s) {
+                        uint64_t* counter, int dtype, hipStream_t s) {
   if (n <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(dropout_fwd_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x,
-                                               (T*)y, mask, n, p, seed, offset));
+                                               (T*)y, mask, n, p, seed, offset, (const uint64_t*)counter));
+  if (counter != nullptr)
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, s, counter, (uint64_t)n);
   DPA_CHECK_HIP(hipGetLastError());
 }
 void dropout_bwd_launch(const void* dy, const uint8_t* mask, void* dx, long n, float p, int dtype, hipStream_t s) {

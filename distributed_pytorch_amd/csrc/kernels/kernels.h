@@ -116,8 +116,9 @@ void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad
 void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
 void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
+// counter (device, optional): RNG stream position read by the kernel and advanced by n afterwards
 void dropout_fwd_launch(const void* x, void* y, uint8_t* mask, long n, float p, uint64_t seed,
-                        uint64_t offset, int dtype, hipStream_t s);
+                        uint64_t offset, uint64_t* counter, int dtype, hipStream_t s);
 void dropout_bwd_launch(const void* dy, const uint8_t* mask, void* dx, long n, float p, int dtype,
                         hipStream_t s);
 void cast_launch(const void* x, int in_dtype, void* y, int out_dtype, long n, hipStream_t s);

@@ -272,6 +272,14 @@ class _Run:
         self.is_main, self.writer = is_main, writer
         self.global_step = 0
         self.jsonl = None
+        self.graphed = None
+        if getattr(args, "hip_graph", False):
+            if device.type == "cuda" and world == 1:
+                from .utils.graph import GraphedTrainStep
+
+                self.graphed = GraphedTrainStep(model, optimizer)
+            elif is_main:
+                print("=> --hip-graph applies to single-process GPU runs; this run executes eagerly")
         if is_main and args.out_dir:
             os.makedirs(args.out_dir, exist_ok=True)
             self.jsonl = open(os.path.join(args.out_dir, "metrics.jsonl"), "a")
@@ -320,15 +328,19 @@ class _Run:
             if script == "apex":
                 lr = schedule.adjust_learning_rate_iter(self.optimizer, epoch, i, n_iter, args)
             data_time.update(time.time() - end)
-            with profiling.range_("forward"):
-                output = self.model(images)
-                loss, rec = F.loss_and_metrics(output, target)
-            self.optimizer.zero_grad()
-            with profiling.range_("backward"):
-                with amp.scale_loss(loss, self.optimizer) as scaled:
-                    scaled.backward()
-            with profiling.range_("step"):
-                self.optimizer.step()
+            if self.graphed is not None:
+                with profiling.range_("graphed_step"):
+                    loss, rec = self.graphed(images, target)
+            else:
+                with profiling.range_("forward"):
+                    output = self.model(images)
+                    loss, rec = F.loss_and_metrics(output, target)
+                self.optimizer.zero_grad()
+                with profiling.range_("backward"):
+                    with amp.scale_loss(loss, self.optimizer) as scaled:
+                        scaled.backward()
+                with profiling.range_("step"):
+                    self.optimizer.step()
             dm.update(rec)
             self.global_step += 1
             win_iters += 1

@@ -698,20 +698,28 @@ def add_relu(a, b):
     return _AddReluFn.apply(a, b)
 
 
-_dropout_offset = 0
+_dropout_counters: Dict[int, torch.Tensor] = {}
+
+
+def _dropout_counter(device) -> torch.Tensor:
+    """Device-resident RNG stream position (advanced by the kernel launch itself): masks stay fresh when the
+    step is replayed from a hipGraph, where host-side offsets would be frozen at capture time."""
+    t = _dropout_counters.get(device.index)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _dropout_counters[device.index] = t
+    return t
 
 
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p):
-        global _dropout_offset
         x = x if x.is_contiguous() else x.contiguous()
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        C().dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), p, seed, _dropout_offset, _dt(x),
-                        _stream())
-        _dropout_offset += x.numel()
+        C().dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), p, seed, 0,
+                        _dropout_counter(x.device).data_ptr(), _dt(x), _stream())
         ctx.save_for_backward(mask)
         ctx.p = p
         return y
@@ -1034,8 +1042,9 @@ class SgdPlan:
     def matches(self, opt) -> bool:
         return self.sig == self.signature(opt)
 
-    def launch(self, opt, scaler) -> None:
-        st = _stream()
+    def sync_hyper(self, opt) -> None:
+        """Refresh the device-side hyper-parameter array (lr, momentum, wd, dampening, nesterov, first-step)
+        when the host values changed.  Separate from launch() so a captured step never records the copy."""
         for gt in self.groups:
             group = gt["group"]
             first = 1.0 if opt._steps == 0 else 0.0
@@ -1044,6 +1053,12 @@ class SgdPlan:
             if gt["hyper_host"] != host:
                 gt["hyper"].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
                 gt["hyper_host"] = host
+
+    def launch(self, opt, scaler) -> None:
+        st = _stream()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper(opt)
+        for gt in self.groups:
             inv = found = 0
             if scaler is not None and not scaler.is_identity:
                 inv, found = scaler.inv_scale.data_ptr(), scaler.found_inf.data_ptr()

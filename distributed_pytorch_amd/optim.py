@@ -170,6 +170,18 @@ class FusedSGD(Optimizer):
         self._plan.launch(self, scaler)
         _amp.mark_copies_written(self._plan.params_with_copies)
 
+    # ------------------------------------------------------------------ hipGraph support (utils/graph.py)
+    def sync_hyper(self) -> None:
+        if self._plan is not None:
+            self._plan.sync_hyper(self)
+
+    def after_graph_replay(self) -> None:
+        """A replayed step ran the captured kernels only: advance the host-side bookkeeping."""
+        from .ops import hip_ops
+
+        self._steps += 1
+        hip_ops.bump_generation()
+
     # ------------------------------------------------------------------ torch-compatible state
     def state_dict(self):
         sd = super().state_dict()

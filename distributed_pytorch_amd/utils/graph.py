@@ -1,0 +1,100 @@
+"""hipGraph capture of the whole training step (``--hip-graph``).
+
+One ResNet-50 step is ~700 kernel launches issued from Python; at batch 256 the GPU is the bottleneck,
+but small models / small per-GPU batches are launch bound.  After a few eager warm-up steps (which build
+every cache: weight copies, tap tables, the SGD tensor table, the gradient arena) the sequence
+
+    zero_grad -> forward -> loss+metrics -> backward -> fused SGD step (-> loss-scaler update)
+
+is captured ONCE into a HIP graph (``torch.cuda.CUDAGraph`` == hipGraph on ROCm; our kernels are launched
+on torch's current stream, so stream capture records them like any ATen kernel) and replayed per step
+with the batch copied into static input buffers.  Host-side values that change between steps (learning
+rate, momentum, ...) live in a small device array that is refreshed BEFORE the replay, so schedules keep
+working.  Single-process only: RCCL collectives on the reducer's side stream are not captured (DDP runs
+eagerly), and any capture failure falls back to eager execution with a warning.
+
+The reference has no equivalent (``cudnn.benchmark`` autotuning is its only launch-side knob,
+nd_imagenet.py:200, imagenet_ddp_apex.py:110) -- SURVEY.md section 7 "HIP streams and graphs".
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from .. import amp
+from ..ops import functional as F
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, warmup: int = 3, enabled: bool = True):
+        self.model, self.optimizer = model, optimizer
+        self.warmup = max(2, warmup)
+        self.enabled = enabled
+        self.graph = None
+        self.key = None
+        self._seen_key, self._seen = None, 0
+        self.replays = 0
+
+    # the eager step, also what gets captured
+    def _step(self, images, target):
+        output = self.model(images)
+        loss, rec = F.loss_and_metrics(output, target)
+        self.optimizer.zero_grad()
+        with amp.scale_loss(loss, self.optimizer) as scaled:
+            scaled.backward()
+        self.optimizer.step()
+        return loss, rec
+
+    def _capture(self, images, target):
+        self.static_x = images.clone()
+        self.static_t = target.clone()
+        if getattr(images, "_dpa_nhwc", False):      # the prefetcher's "already normalised NHWC" tag
+            self.static_x._dpa_nhwc = True
+        sync = getattr(self.optimizer, "sync_hyper", None)
+        if sync is not None:
+            sync()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, rec = self._step(self.static_x, self.static_t)
+        self.graph, self.loss, self.rec = g, loss, rec
+        self.key = self._key(images, target)
+
+    @staticmethod
+    def _key(images, target):
+        return (tuple(images.shape), images.dtype, tuple(target.shape), target.dtype,
+                bool(getattr(images, "_dpa_nhwc", False)))
+
+    def __call__(self, images, target):
+        if not self.enabled or not images.is_cuda:
+            return self._step(images, target)
+        key = self._key(images, target)
+        if self.graph is None:
+            if key != self._seen_key:
+                self._seen_key, self._seen = key, 0
+            self._seen += 1
+            if self._seen <= self.warmup:
+                return self._step(images, target)
+            try:
+                self._capture(images, target)
+            except Exception as exc:  # noqa: BLE001
+                warnings.warn("hipGraph capture of the training step failed (%s: %s); running eagerly"
+                              % (type(exc).__name__, exc))
+                self.enabled = False
+                self.graph = None
+                torch.cuda.synchronize()
+                return self._step(images, target)
+        if key != self.key:                      # ragged last batch
+            return self._step(images, target)
+        self.static_x.copy_(images, non_blocking=True)
+        self.static_t.copy_(target, non_blocking=True)
+        sync = getattr(self.optimizer, "sync_hyper", None)
+        if sync is not None:
+            sync()
+        self.graph.replay()
+        done = getattr(self.optimizer, "after_graph_replay", None)
+        if done is not None:
+            done()
+        self.replays += 1
+        return self.loss, self.rec

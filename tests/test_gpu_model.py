@@ -142,3 +142,39 @@ def test_syncbn_gpu_path_equals_plain_bn_on_one_rank():
     assert torch.allclose(stats[0][0], stats[1][0], atol=1e-5) and torch.allclose(stats[0][1], stats[1][1], atol=1e-4)
     for a, b in ((xs[0].grad, xs[1].grad), (ws[0].grad, ws[1].grad), (bs[0].grad, bs[1].grad)):
         assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2 * float(a.float().abs().max()))
+
+
+def test_hip_graph_step_matches_eager_training():
+    """--hip-graph: the captured + replayed step leaves exactly the eager trajectory (same kernels, same order),
+    and the learning rate can still change between replays."""
+    import copy
+
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.utils.graph import GraphedTrainStep
+
+    amp.state().reset()
+    torch.manual_seed(0)
+    base = models.create_model("resnet18", num_classes=10).cuda().train()
+    xs = [torch.randint(0, 256, (8, 64, 64, 3), dtype=torch.uint8, device="cuda") for _ in range(8)]
+    ts = [torch.randint(0, 10, (8,), device="cuda") for _ in range(8)]
+    results = []
+    for use_graph in (False, True):
+        amp.state().reset()
+        model = copy.deepcopy(base)
+        opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        model, opt = amp.initialize(model, opt, opt_level="O2", dtype="bf16")
+        stepper = GraphedTrainStep(model, opt, warmup=2, enabled=use_graph)
+        losses = []
+        for i, (x, t) in enumerate(zip(xs, ts)):
+            if i == 5:
+                opt.param_groups[0]["lr"] = 0.01
+            loss, _ = stepper(x, t)
+            losses.append(float(loss))
+        if use_graph:
+            assert stepper.replays == 6, "capture did not happen (%d replays)" % stepper.replays
+        results.append((losses, [p.detach().float().clone() for p in model.parameters()]))
+    (l0, p0), (l1, p1) = results
+    assert l0 == pytest.approx(l1, rel=1e-5, abs=1e-6), (l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
