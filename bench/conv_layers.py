@@ -28,10 +28,30 @@ R50 = [
 
 
 def timeit(fn, iters=10):
-    for _ in range(3):
+    """GPU time per call.  The calls are captured into a hipGraph and replayed: a Python-launched sequence is
+    CPU bound below ~50 us per call (autograd Function + allocator + pybind), which hid every kernel-side
+    change on the small layers."""
+    for _ in range(2):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+    except Exception:  # noqa: BLE001
+        g = None
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if g is not None:
+        g.replay()
+        torch.cuda.synchronize()
+        s.record()
+        g.replay()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / (2 * iters) * 1e-3
     s.record()
     for _ in range(iters):
         fn()
@@ -71,6 +91,35 @@ def sweep(args, hip_ops):
                 flush=True)
     for kind, (a, b) in totals.items():
         print("weighted %s: auto %.2f ms, best-per-layer %.2f ms" % (kind, a, b))
+
+
+def sweep_wgrad(args, hip_ops):
+    C = hip_ops.C()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    N = args.batch
+    ncfg = C.wgrad_num_configs()
+    C.wgrad_set_target_blocks(args.target_blocks)
+    print("wgrad ms per call (kernel + slab fold); columns = config ids 0..%d, 'a' = automatic; target blocks %d" % (
+        ncfg - 1, args.target_blocks))
+    tot = [0.0, 0.0]
+    for (H, Cin, Cout, k, s, p, cnt) in R50:
+        Cx = Cin if Cin % 8 == 0 else 8
+        OH = (H + 2 * p - k) // s + 1
+        x = torch.randn(N, H, H, Cx, device="cuda").to(dt)
+        w = (torch.randn(Cout, Cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, OH, OH, Cout, device="cuda").to(dt)
+        fn = lambda: hip_ops.conv_wgrad(dy, x, w, (s, s), (p, p))
+        ts = []
+        for cfg in list(range(ncfg)) + [-1]:
+            C.wgrad_force_config(cfg)
+            ts.append(timeit(fn, 6) * 1e3)
+        C.wgrad_force_config(-1)
+        best = min(range(ncfg), key=lambda i: ts[i])
+        tot[0] += ts[-1] * cnt
+        tot[1] += ts[best] * cnt
+        print("%3dx%-3d %4d->%-4d k%d s%d x%d  %s  a=%.3f best=%d (%.3f)" % (
+            H, H, Cin, Cout, k, s, cnt, " ".join("%.3f" % t for t in ts[:-1]), ts[-1], best, ts[best]), flush=True)
+    print("weighted wgrad: auto %.2f ms, best-per-layer %.2f ms" % tuple(tot))
 
 
 def sweep_wgrad(args, hip_ops):

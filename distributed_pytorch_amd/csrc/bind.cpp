@@ -60,8 +60,10 @@ PYBIND11_MODULE(_C, m) {
   });
   m.def("wgrad",
         [](uintptr_t dY, uintptr_t X, uintptr_t slab, uintptr_t taps, int M, int N, int Cred, int ntaps, int ldy,
-           int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int dtype, uintptr_t stream) {
+           int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int taps_zero, int dtype,
+           uintptr_t stream) {
           WgradParams p;
+          p.taps_zero = taps_zero;
           p.dY = ptr<const void>(dY);
           p.X = ptr<const void>(X);
           p.slab = ptr<float>(slab);

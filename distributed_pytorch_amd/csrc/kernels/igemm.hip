@@ -270,27 +270,61 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   const int cpt = p.Cred / VEC;                        // chunks per tap
   const int nk = ALIGNED ? p.ntaps * kpt : (p.ntaps * cpt + CPR - 1) / CPR;
 
-  auto load_tile = [&](int kt) {
-    int dy, dx, cA;
-    size_t kB;
-    bool tok = true;
-    if (ALIGNED) {
-      const int t = kt / kpt;
-      const int c0 = (kt - t * kpt) * BK;
-      dy = p.taps[3 * t + 0];
-      dx = p.taps[3 * t + 1];
-      cA = c0 + ch * VEC;
-      kB = (size_t)p.taps[3 * t + 2] * p.Cred + cA;
-    } else {
-      const int kc = kt * CPR + ch;
-      int t = kc / cpt;
-      cA = (kc - t * cpt) * VEC;
-      tok = t < p.ntaps;
-      t = tok ? t : 0;
-      dy = p.taps[3 * t + 0];
-      dx = p.taps[3 * t + 1];
-      kB = (size_t)p.taps[3 * t + 2] * p.Cred + cA;
+  // ALIGNED (Cred % BK == 0, operands < 4 GiB -- checked on the host): the gather address of a row only
+  // changes when the TAP changes, so the per-row work (bounds test, pixel offset) is done once per tap into
+  // 32-bit byte offsets; a K tile inside the tap is "scalar base + offset" loads with no vector address
+  // arithmetic at all.  Counters showed the old per-tile 64-bit address math made the loop issue bound.
+  uint32_t aoff[A_IT], amask[A_IT], boff[B_IT], bmask[B_IT];
+  size_t kb_tap = 0;
+  int lt_tap = 0, lt_kc = 0;                           // next K tile to load: tap, tile inside the tap
+  if (ALIGNED) {
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      boff[i] = (uint32_t)((brow[i] + ch * VEC) * sizeof(T));
+      bmask[i] = bok[i] ? 0xffffffffu : 0u;
     }
+  }
+  auto set_tap = [&](int t) {
+    // wave-uniform values: keep them in SGPRs so the per-tile bases stay scalar
+    const int dy = __builtin_amdgcn_readfirstlane(p.taps[3 * t + 0]);
+    const int dx = __builtin_amdgcn_readfirstlane(p.taps[3 * t + 1]);
+    kb_tap = (size_t)__builtin_amdgcn_readfirstlane(p.taps[3 * t + 2]) * p.Cred;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const uint32_t pix = (uint32_t)(pbase[i] + iy * p.IW + ix);
+      aoff[i] = ok ? (pix * (uint32_t)p.lda + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T) : 0u;
+      amask[i] = ok ? 0xffffffffu : 0u;
+    }
+  };
+
+  auto load_tile = [&](int kt) {
+    if (ALIGNED) {
+      if (lt_kc == 0) set_tap(lt_tap);
+      const int c0 = lt_kc * BK;
+      const char* Ak = Ag + (size_t)c0 * sizeof(T);
+      const char* Bk = Bg + (kb_tap + c0) * sizeof(T);
+#pragma unroll
+      // unconditional loads (out-of-image rows read offset 0 and are masked when the tile is written to
+      // LDS, after the MFMAs of the current tile): no branch and no wait between the loads and the compute
+      for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + aoff[i]);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bk + boff[i]);
+      if (++lt_kc == kpt) {
+        lt_kc = 0;
+        ++lt_tap;
+      }
+      return;
+    }
+    const int kc = kt * CPR + ch;
+    int t = kc / cpt;
+    const int cA = (kc - t * cpt) * VEC;
+    const bool tok = t < p.ntaps;
+    t = tok ? t : 0;
+    const int dy = p.taps[3 * t + 0];
+    const int dx = p.taps[3 * t + 1];
+    const size_t kB = (size_t)p.taps[3 * t + 2] * p.Cred + cA;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int iy = iy0[i] + dy, ix = ix0[i] + dx;
@@ -311,12 +345,16 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = (tid + i * 256) / CPR;
-      *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = ra[i];
+      uint4 v = ra[i];
+      if (ALIGNED) { v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i]; }
+      *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = (tid + i * 256) / CPR;
-      *reinterpret_cast<uint4*>(sb + row * LDR + ch * 16) = rb[i];
+      uint4 v = rb[i];
+      if (ALIGNED) { v.x &= bmask[i]; v.y &= bmask[i]; v.z &= bmask[i]; v.w &= bmask[i]; }
+      *reinterpret_cast<uint4*>(sb + row * LDR + ch * 16) = v;
     }
   };
 
@@ -649,10 +687,14 @@ template <typename T, typename TOut>
 void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
   constexpr int ES = (int)sizeof(T);
   constexpr bool EXT = sizeof(T) == 2 && std::is_same<T, TOut>::value;   // tuning hook applies here only
-  const bool aligned = p.Cred % (64 / ES) == 0;
+  // the aligned kernels address both operands with 32-bit byte offsets
+  const long nb = p.M / (long)p.div_ohow.d + 1;
+  const bool fits32 = (double)nb * p.IH * p.IW * p.lda * ES < 4294967296.0 &&
+                      (double)p.N * p.ldb * ES < 4294967296.0;
+  const bool aligned = p.Cred % (64 / ES) == 0 && fits32;
   const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
   if (!aligned) {
-    if (cfg == 2) launch_cfg<T, TOut, 128, 128, 64, 2, false>(p, stream);
+    if (p.N > 64) launch_cfg<T, TOut, 128, 128, 64, 2, false>(p, stream);
     else launch_cfg<T, TOut, 128, 64, 64, 2, false>(p, stream);
     return;
   }

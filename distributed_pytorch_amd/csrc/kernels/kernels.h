@@ -42,6 +42,7 @@ struct WgradParams {
   int ldy, ldx;
   int IH, IW, SY, SX;
   int splits, pix_per_split;
+  int taps_zero;       // every tap is (0, 0): a 1x1 convolution without padding (enables the linear fast path)
   FastDiv div_ohow, div_ow;
 };
 void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);

@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace dpa {
 namespace {
@@ -31,24 +32,28 @@ __device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
   return r;
 }
 
-template <typename T, int BI, int BJ, int KB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+// LIN: 1x1 / stride 1 / no padding and both operands < 4 GiB (host checked): the im2col row of pixel m is row m
+// of X, so both operands are walked with 32-bit byte offsets that advance by a constant per K tile -- no
+// divisions, no 64-bit address arithmetic in the loop (PMC counters showed the generic gather issue bound).
+template <typename T, int BI, int BJ, int KB, int WI, int WJ, bool LIN, int PF>
+__global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p) {
+  constexpr int NT = 64 * WI * WJ;                     // WI x WJ waves, each owns a (BI/WI) x (BJ/WJ) sub-tile
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BKP = KB / (int)sizeof(T);             // pixels per K tile (KB bytes of K per column)
   constexpr int LDP = BI * (int)sizeof(T) + 64;        // row stride = 64 (mod 128): conflict-free tr reads
   constexpr int LDQ = BJ * (int)sizeof(T) + 64;
   constexpr int CPP = BI * (int)sizeof(T) / 16, CPQ = BJ * (int)sizeof(T) / 16;
-  constexpr int P_IT = BKP * CPP / 256, Q_IT = BKP * CPQ / 256;
-  constexpr int WTI = BI / 2, WTJ = BJ / 2;
+  constexpr int P_IT = BKP * CPP / NT, Q_IT = BKP * CPQ / NT;
+  constexpr int WTI = BI / WI, WTJ = BJ / WJ;
   constexpr int MI = WTI / 32, NJ = WTJ / 32;
   constexpr int STAGE = BKP * (LDP + LDQ);
   static_assert(P_IT >= 1 && Q_IT >= 1 && MI >= 1 && NJ >= 1, "tile too small");
-  static_assert(256 % CPP == 0 && 256 % CPQ == 0, "chunk mapping");
+  static_assert(NT % CPP == 0 && NT % CPQ == 0, "chunk mapping");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = wave >> 1, wj = wave & 1;
+  const int wi = wave / WJ, wj = wave % WJ;
 
   const uint32_t tiles_i = (p.N + BI - 1) / BI, tiles_j = (p.Ktot + BJ - 1) / BJ;
   const uint32_t tiles = tiles_i * tiles_j;
@@ -77,19 +82,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     qdx = p.taps[3 * t + 1];
   }
 
-  uint4 rp[P_IT], rq[Q_IT];
-  auto load_tile = [&](int m_base) {
+  // two register sets: tiles kt+1 and kt+2 are in flight while tile kt is consumed from LDS (one tile ahead
+  // left every workgroup waiting a full memory latency per 8 MFMAs)
+  uint4 rp[PF][P_IT], rq[PF][Q_IT];
+  uint32_t poff[P_IT], qoff[Q_IT], pmask[PF][P_IT], qmask[PF][Q_IT];
+  if (LIN) {
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i)
+      poff[i] = (uint32_t)(((uint32_t)(m_begin + (tid + i * NT) / CPP) * (uint32_t)p.ldy + i0 + cp * VEC) * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < Q_IT; ++i)
+      qoff[i] = (uint32_t)(((uint32_t)(m_begin + (tid + i * NT) / CPQ) * (uint32_t)p.ldx + kcol) * sizeof(T));
+  }
+  const uint32_t pstep = (uint32_t)(BKP * p.ldy * (int)sizeof(T)), qstep = (uint32_t)(BKP * p.ldx * (int)sizeof(T));
+  auto load_tile = [&](int m_base, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+    if (LIN) {
+      // unconditional loads (rows past the range read offset 0 and are masked at the LDS write)
+#pragma unroll
+      for (int i = 0; i < P_IT; ++i) {
+        const bool ok = pok && m_base + (tid + i * NT) / CPP < m_end;
+        pmask[S][i] = ok ? 0xffffffffu : 0u;
+        rp[S][i] = *reinterpret_cast<const uint4*>(Yg + (ok ? poff[i] : 0u));
+        poff[i] += pstep;
+      }
+#pragma unroll
+      for (int i = 0; i < Q_IT; ++i) {
+        const bool ok = qok && m_base + (tid + i * NT) / CPQ < m_end;
+        qmask[S][i] = ok ? 0xffffffffu : 0u;
+        rq[S][i] = *reinterpret_cast<const uint4*>(Xg + (ok ? qoff[i] : 0u));
+        qoff[i] += qstep;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
-      const int row = (tid + i * 256) / CPP;
+      const int row = (tid + i * NT) / CPP;
       const int m = m_base + row;
       const bool ok = pok && m < m_end;
-      rp[i] = ok ? *reinterpret_cast<const uint4*>(Yg + ((size_t)m * p.ldy + i0 + cp * VEC) * sizeof(T))
-                 : make_uint4(0, 0, 0, 0);
+      rp[S][i] = ok ? *reinterpret_cast<const uint4*>(Yg + ((size_t)m * p.ldy + i0 + cp * VEC) * sizeof(T))
+                    : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < Q_IT; ++i) {
-      const int row = (tid + i * 256) / CPQ;
+      const int row = (tid + i * NT) / CPQ;
       const uint32_t m = m_base + row;
       bool ok = qok && (int)m < m_end;
       size_t off = 0;
@@ -102,21 +138,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
         off = ((size_t)((int)n * p.IH * p.IW + iy * p.IW + ix) * p.ldx + qc) * sizeof(T);
       }
-      rq[i] = ok ? *reinterpret_cast<const uint4*>(Xg + off) : make_uint4(0, 0, 0, 0);
+      rq[S][i] = ok ? *reinterpret_cast<const uint4*>(Xg + off) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     unsigned char* sp = smem + buf * STAGE;
     unsigned char* sq = sp + BKP * LDP;
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
-      const int row = (tid + i * 256) / CPP;
-      *reinterpret_cast<uint4*>(sp + row * LDP + cp * 16) = rp[i];
+      const int row = (tid + i * NT) / CPP;
+      uint4 v = rp[S][i];
+      if (LIN) { v.x &= pmask[S][i]; v.y &= pmask[S][i]; v.z &= pmask[S][i]; v.w &= pmask[S][i]; }
+      *reinterpret_cast<uint4*>(sp + row * LDP + cp * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < Q_IT; ++i) {
-      const int row = (tid + i * 256) / CPQ;
-      *reinterpret_cast<uint4*>(sq + row * LDQ + cq * 16) = rq[i];
+      const int row = (tid + i * NT) / CPQ;
+      uint4 v = rq[S][i];
+      if (LIN) { v.x &= qmask[S][i]; v.y &= qmask[S][i]; v.z &= qmask[S][i]; v.w &= qmask[S][i]; }
+      *reinterpret_cast<uint4*>(sq + row * LDQ + cq * 16) = v;
     }
   };
 
@@ -132,15 +173,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int g = lane >> 4, gi = lane & 15;
 
-  if (nk > 0) {
-    load_tile(m_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(m_begin + (kt + 1) * BKP);
+  auto compute = [&](int cur) {
     const unsigned char* sp = smem + cur * STAGE;
     const unsigned char* sq = sp + BKP * LDP;
     if constexpr (sizeof(T) == 2) {
@@ -196,8 +229,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
+  };
+
+  constexpr std::integral_constant<int, 0> kSet0{};
+  constexpr std::integral_constant<int, 1> kSet1{};
+  // Tiles past the range load nothing (all rows masked / zero filled) and add zeros, so the loop needs no
+  // tail cases: one straight-line body of two K tiles keeps a single live copy of the accumulators.
+  // PF = K tiles in flight in registers while one is consumed from LDS (1: one register set, 2: two).
+  load_tile(m_begin, kSet0);
+  if constexpr (PF == 2) load_tile(m_begin + BKP, kSet1);
+  store_tile(0, kSet0);
+  __syncthreads();
+
+  // LDS buffer b holds tile kt (b = kt & 1)
+  for (int kt = 0; kt < nk; kt += 2) {
+    if constexpr (PF == 2) {        // register set (kt+1)&1 holds tile kt+1, the other one is free
+      load_tile(m_begin + (kt + 2) * BKP, kSet0);
+      compute(0);
+      store_tile(1, kSet1);
+      __syncthreads();
+      load_tile(m_begin + (kt + 3) * BKP, kSet1);
+      compute(1);
+      store_tile(0, kSet0);
+      __syncthreads();
+    } else {
+      load_tile(m_begin + (kt + 1) * BKP, kSet0);
+      compute(0);
+      store_tile(1, kSet0);
+      __syncthreads();
+      load_tile(m_begin + (kt + 2) * BKP, kSet0);
+      compute(1);
+      store_tile(0, kSet0);
+      __syncthreads();
+    }
   }
 
   // acc[a][b][r]: i = wi*WTI + a*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wj*WTJ + b*32 + l31
@@ -263,40 +327,55 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-template <typename T, int BI, int BJ, int KB>
+template <typename T, int BI, int BJ, int KB, int WI = 2, int WJ = 2, int PF = 1>
 void launch_cfg(const WgradParams& p, hipStream_t stream) {
   constexpr int BKP = KB / (int)sizeof(T);
   constexpr int lds = 2 * BKP * ((BI + BJ) * (int)sizeof(T) + 128);
-  auto kern = wgrad_kernel<T, BI, BJ, KB>;
+  const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
+  const int es = (int)sizeof(T);
+  const long nb = p.M / (long)p.div_ohow.d + 1;
+  const bool lin = p.ntaps == 1 && p.SY == 1 && p.SX == 1 && p.taps_zero &&
+                   (long)p.div_ohow.d == (long)p.IH * p.IW && (int)p.div_ow.d == p.IW &&
+                   (double)p.M * p.ldy * es < 4294967296.0 && (double)nb * p.IH * p.IW * p.ldx * es < 4294967296.0;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  if (lin)
+    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF>), dim3((unsigned)blocks), dim3(64 * WI * WJ), lds,
+                       stream, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF>), dim3((unsigned)blocks), dim3(64 * WI * WJ), lds,
+                       stream, p);
 }
 
 // Tile configurations (output channels x im2col columns x bytes of pixels per K tile); picked per
 // problem shape from measurements (bench/conv_layers.py --sweep-wgrad; wgrad_force_config).
-struct WCfg { int bi, bj, kb; };
+struct WCfg { int bi, bj, kb, threads; };
 constexpr WCfg kWCfgs[] = {
-    {128, 128, 64}, {64, 64, 64}, {64, 256, 64}, {64, 128, 64}, {128, 64, 64},
+    {128, 128, 64, 256}, {64, 64, 64, 256}, {64, 256, 64, 256}, {64, 128, 64, 256}, {128, 64, 64, 256},
+    {256, 256, 64, 512}, {256, 128, 64, 512}, {128, 256, 64, 512},      // 5..7: 8-wave workgroups
+    {128, 128, 64, 256}, {256, 128, 64, 512}, {64, 128, 64, 256},       // 8..10: cfg 0 / 6 / 3 with two tiles in flight
 };
 constexpr int kNumWCfgs = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
 int g_force_wcfg = -1;
 int g_target_blocks = 768;
 
-// From the per-layer sweep (profiles/r1_wgrad_sweep.md): square 128x128 tiles everywhere except the
-// 64-channel layers, where a tile as wide as the short side allows avoids re-reading the long operand.
-// 128-byte K tiles and 256-wide output tiles never won.
+// From the per-layer sweeps (profiles/r1_wgrad_sweep.md, GPU-side timing through hipGraph replay): two K tiles
+// in flight (PF = 2) win on the 1x1 layers, the 8-wave 256x128 tile on the big 3x3 layers (it halves the
+// re-reads of the im2col operand), and the 64-channel layers want a tile as wide as their short side allows.
 int choose_wcfg(long M, int N, int Ktot) {
   (void)M;
   if (g_force_wcfg >= 0 && g_force_wcfg < kNumWCfgs) return g_force_wcfg;
-  if (N <= 64) return Ktot <= 64 ? 1 : (Ktot <= 256 ? 3 : 2);
+  if (N <= 64) return Ktot <= 64 ? 1 : (Ktot <= 256 ? 10 : 2);
   if (Ktot <= 64) return 4;
-  return 0;
+  if (Ktot >= 2304 && N >= 256) return 9;
+  if (Ktot >= 1152 && N <= 128) return 0;
+  return 8;
 }
 
 template <typename T>
@@ -307,6 +386,12 @@ void dispatch(const WgradParams& p, hipStream_t stream) {
     case 2: launch_cfg<T, 64, 256, 64>(p, stream); return;
     case 3: launch_cfg<T, 64, 128, 64>(p, stream); return;
     case 4: launch_cfg<T, 128, 64, 64>(p, stream); return;
+    case 5: launch_cfg<T, 256, 256, 64, 2, 4>(p, stream); return;
+    case 6: launch_cfg<T, 256, 128, 64, 4, 2>(p, stream); return;
+    case 7: launch_cfg<T, 128, 256, 64, 2, 4>(p, stream); return;
+    case 8: launch_cfg<T, 128, 128, 64, 2, 2, 2>(p, stream); return;
+    case 9: launch_cfg<T, 256, 128, 64, 4, 2, 2>(p, stream); return;
+    case 10: launch_cfg<T, 64, 128, 64, 2, 2, 2>(p, stream); return;
     default: throw std::logic_error("wgrad: bad tile configuration");
   }
 }
@@ -322,7 +407,8 @@ int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split) 
   const int bkp = c.kb / (dtype == kF32 ? 4 : 2);
   const long tiles = (long)ceil_div(N, c.bi) * ceil_div(Ktot, c.bj);
   // aim for ~3 workgroups per CU, keep >= 8 K tiles per workgroup, and bound the slab size
-  long splits = (g_target_blocks + tiles - 1) / tiles;
+  const long target = (long)g_target_blocks * 256 / c.threads;     // same number of waves in flight
+  long splits = (target + tiles - 1) / tiles;
   const long max_by_work = (M + 8l * bkp - 1) / (8l * bkp);
   if (splits > max_by_work) splits = max_by_work;
   const long out_elems = (long)N * Ktot;

@@ -371,7 +371,7 @@ def conv_wgrad(dy, x, weight, stride, padding):
     taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
     st = _stream()
     C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
-              sh, sw, OH, OW, splits, pps, _dt(dy), st)
+              sh, sw, OH, OW, splits, pps, 1 if (R * S == 1 and ph == 0 and pw == 0) else 0, _dt(dy), st)
     gdtype = weight.dtype
     sink = grad_sink.sink_of(weight)
     if Cx == Cw and sink is not None and _flat_same_layout(sink.view, weight) \
@@ -813,7 +813,7 @@ class _LinearFn(torch.autograd.Function):
             splits, pps = C().wgrad_choose_splits(M, outp, in_f, _dt(cdt))
             slab = torch.empty((splits, outp, in_f), dtype=torch.float32, device=dy.device)
             C().wgrad(dyp.data_ptr(), x2.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, outp, in_f, 1,
-                      outp, in_f, 1, 1, 1, 1, 1, 1, splits, pps, _dt(cdt), st)
+                      outp, in_f, 1, 1, 1, 1, 1, 1, splits, pps, 1, _dt(cdt), st)
             sink = grad_sink.sink_of(weight)
             if sink is not None and sink.view.is_contiguous() and outp == out_f:
                 # the slab fold writes the gradient straight into the parameter's bucket view
