@@ -27,8 +27,13 @@ PYBIND11_MODULE(_C, m) {
         [](uintptr_t A, uintptr_t B, uintptr_t C, uintptr_t R, uintptr_t bias, uintptr_t stats, uintptr_t taps, int M,
            int N,
            int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
-           int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream) {
+           int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream,
+           uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu) {
           IgemmParams p;
+          p.bn_x = ptr<const void>(bn_x);
+          p.bn_z = ptr<const void>(bn_z);
+          p.bn_coef = ptr<const float>(bn_coef);
+          p.bn_relu = bn_relu;
           p.A = ptr<const void>(A);
           p.B = ptr<const void>(B);
           p.C = ptr<void>(C);
@@ -44,7 +49,14 @@ PYBIND11_MODULE(_C, m) {
           p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
           p.div_ow = make_fastdiv((uint32_t)OW);
           igemm_launch(p, dtype, out_dtype, st(stream));
-        });
+        },
+        py::arg("A"), py::arg("B"), py::arg("C"), py::arg("R"), py::arg("bias"), py::arg("stats"), py::arg("taps"),
+        py::arg("M"), py::arg("N"), py::arg("Cred"), py::arg("ntaps"), py::arg("lda"), py::arg("ldb"), py::arg("ldc"),
+        py::arg("IH"), py::arg("IW"), py::arg("SY"), py::arg("SX"), py::arg("OH"), py::arg("OW"), py::arg("OHF"),
+        py::arg("OWF"), py::arg("OSY"), py::arg("OSX"), py::arg("OY0"), py::arg("OX0"), py::arg("flags"),
+        py::arg("dtype"), py::arg("out_dtype"), py::arg("stream"), py::arg("bn_x") = 0, py::arg("bn_z") = 0,
+        py::arg("bn_coef") = 0, py::arg("bn_relu") = 0);
+  m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
   m.def("igemm_tile_m", &igemm_tile_m);
   m.def("igemm_stats_rows", &igemm_stats_rows);
   m.def("igemm_force_config", &igemm_force_config);
@@ -101,6 +113,7 @@ PYBIND11_MODULE(_C, m) {
     bn_eval_coeffs_launch(ptr<const float>(gamma), ptr<const float>(beta), ptr<const float>(rm), ptr<const float>(rv),
                           eps, C, ptr<float>(scale), ptr<float>(shift), st(s));
   });
+  m.def("bn_set_tuning", &bn_set_tuning);
   m.def("bn_apply", [](uintptr_t x, uintptr_t res, uintptr_t y, long M, int C, int dtype, uintptr_t scale,
                        uintptr_t shift, int relu, uintptr_t s) {
     bn_apply_launch(ptr<const void>(x), ptr<const void>(res), ptr<void>(y), M, C, dtype, ptr<const float>(scale),

@@ -66,33 +66,49 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   }
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min(M, r_begin + rows_per_block);
-  if (active) {
-    for (long r = r_begin + rl; r < r_end; r += rp) {
-      const size_t off = (size_t)r * C + c0;
-      Vec16<T> va;
-      va.load(a + off);
-      if (MODE == 0) {
+  auto accumulate = [&](const Vec16<T>& va, const Vec16<T>& vx, const Vec16<T>& vy) {
+    if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const float f = va.get(j);
-          s1[j] += f;
-          s2[j] += f * f;
-        }
-      } else {
-        Vec16<T> vx, vy;
-        vx.load(x + off);
-        if (relu == 1) vy.load(y + off);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float d = va.get(j);
-          const float xv = vx.get(j);
-          if (relu == 1 && !(vy.get(j) > 0.f)) d = 0.f;
-          if (relu == 2 && !(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
-          const float xh = (xv - mu[j]) * is[j];
-          s1[j] += d;
-          s2[j] += d * xh;
-        }
+      for (int j = 0; j < VEC; ++j) {
+        const float f = va.get(j);
+        s1[j] += f;
+        s2[j] += f * f;
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float d = va.get(j);
+        const float xv = vx.get(j);
+        if (relu == 1 && !(vy.get(j) > 0.f)) d = 0.f;
+        if (relu == 2 && !(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
+        const float xh = (xv - mu[j]) * is[j];
+        s1[j] += d;
+        s2[j] += d * xh;
+      }
+    }
+  };
+  if (active) {
+    long r = r_begin + rl;
+    // 4 rows per trip, every load issued before the first use (the summation order stays fixed)
+    for (; r + 3 * rp < r_end; r += 4 * rp) {
+      Vec16<T> va[4], vx[4], vy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t off = (size_t)(r + u * rp) * C + c0;
+        va[u].load(a + off);
+        if (MODE == 1) vx[u].load(x + off);
+        if (MODE == 1 && relu == 1) vy[u].load(y + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(va[u], vx[u], vy[u]);
+    }
+    for (; r < r_end; r += rp) {
+      const size_t off = (size_t)r * C + c0;
+      Vec16<T> va, vx, vy;
+      va.load(a + off);
+      if (MODE == 1) vx.load(x + off);
+      if (MODE == 1 && relu == 1) vy.load(y + off);
+      accumulate(va, vx, vy);
     }
   }
 #pragma unroll
@@ -202,7 +218,10 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, f
   }
 }
 
-template <typename T>
+int g_bn_grid = 256 * 8;     // tuning hooks (bench/bn_layers.py): workgroups of the streaming kernels, unroll
+int g_bn_unroll = 1;
+
+template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, long nchunks, int cc,
                                                        const float* __restrict__ scale,
@@ -215,6 +234,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   int c0 = (int)(i % cc) * VEC;
   load_coef<VEC>(scale, c0, scv);
   load_coef<VEC>(shift, c0, shv);
+  if (U > 1 && fixed) {
+    // U chunks per thread per trip, all loads issued before the first use: more bytes in flight per wave
+    for (; i + (U - 1) * stride < nchunks; i += U * stride) {
+      Vec16<T> vx[U], vr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) vx[u].load(x + (i + u * stride) * VEC);
+      if (res != nullptr) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) vr[u].load(res + (i + u * stride) * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Vec16<T> vo;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = vx[u].get(j) * scv[j] + shv[j];
+          if (res != nullptr) v += vr[u].get(j);
+          if (relu) v = fmaxf(v, 0.f);
+          vo.set(j, v);
+        }
+        vo.store(y + (i + u * stride) * VEC);
+      }
+    }
+  }
   for (; i < nchunks; i += stride) {
     if (!fixed) {
       c0 = (int)(i % cc) * VEC;
@@ -336,7 +379,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 inline int grid_for(long nchunks) {
   long b = (nchunks + 255) / 256;
-  if (b > 256 * 8) b = 256 * 8;
+  if (b > g_bn_grid) b = g_bn_grid;
   return (int)(b < 1 ? 1 : b);
 }
 
@@ -372,7 +415,7 @@ int bn_partial_rows(long M, int C) {
   // enough row blocks to fill the chip (~4 workgroups per CU over all column groups), >= 64 rows each
   const int gy = ceil_div(C / 4, kBnThreads * 2) > 0 ? ceil_div(C / 8, kBnThreads) : 1;
   long nblk = 1024 / (gy > 0 ? gy : 1);
-  const long max_by_rows = (M + 63) / 64;
+  const long max_by_rows = (M + 31) / 32;       // small tensors: more, shorter row blocks (latency, not bytes)
   if (nblk > max_by_rows) nblk = max_by_rows;
   if (nblk < 1) nblk = 1;
   return (int)nblk;
@@ -431,15 +474,16 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
   const int grid = grid_for(nchunks);
-  if (dtype == kF32)
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x,
-                       (const float*)residual, (float*)y, nchunks, C / vec, scale, shift, relu);
-  else if (dtype == kBF16)
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x,
-                       (const bf16_t*)residual, (bf16_t*)y, nchunks, C / vec, scale, shift, relu);
-  else
-    hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)x,
-                       (const f16_t*)residual, (f16_t*)y, nchunks, C / vec, scale, shift, relu);
+  if (g_bn_unroll >= 4) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu));
+  } else if (g_bn_unroll >= 2) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(grid), dim3(256), 0, s, (const T*)x,
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)x,
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu));
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -471,6 +515,11 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
                                                coef, relu));
   DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_set_tuning(int grid_blocks, int unroll) {
+  g_bn_grid = grid_blocks > 0 ? grid_blocks : 256 * 8;
+  g_bn_unroll = unroll > 0 ? unroll : 1;
 }
 
 }  // namespace dpa

@@ -58,7 +58,8 @@ template <> struct Mma<float> {
 // ---- epilogue shared by both main loops: registers -> LDS tile [pixel][channel] -> 16-byte global
 // stores (+ bias, ReLU, fused accumulate, BatchNorm partial statistics).  All waves must be past their
 // last read of the staging buffers (barrier) and have no LDS-DMA in flight when they enter.
-template <typename TOut, int BM, int BN>
+// BNB (data-gradient launches with kIgemmBnBwd): the BatchNorm-backward partial sums are produced here.
+template <typename TOut, int BM, int BN, bool BNB>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&acc)[BN / 64][BM / 64],
                                                unsigned char* smem, int m0, int n0, int mt) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -77,6 +78,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   // acc[a][b][r]: channel = wn*WTN + a*32 + (r&3) + 8*(r>>2) + 4*lh, pixel = wm*WTM + b*32 + l31
   unsigned char* se = smem;
   const bool relu = p.flags & kIgemmRelu;
+  const int ce = tid % CE;
+  const int ncol = n0 + ce * VECO;
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
 #pragma unroll
@@ -112,12 +115,33 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   }
   __syncthreads();
 
-  const int ce = tid % CE;
-  const int ncol = n0 + ce * VECO;
   float s1[VECO], s2[VECO];
 #pragma unroll
   for (int j = 0; j < VECO; ++j) s1[j] = s2[j] = 0.f;
   char* __restrict__ Cg = reinterpret_cast<char*>(p.C);
+  // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column, and ALL
+  // rows of the extra operands requested at once (inside the store loop each row paid a full memory latency;
+  // the accumulators are dead by now, so the 2 x E_IT vectors cost no occupancy)
+  float bmu[VECO], bis[VECO], bsc[VECO], bsh[VECO];
+  uint4 px[E_IT], pz[E_IT];
+  if constexpr (BNB) {
+#pragma unroll
+    for (int j = 0; j < VECO; ++j) {
+      const int c = ncol + j < p.N ? ncol + j : 0;
+      bmu[j] = p.bn_coef[c];
+      bis[j] = p.bn_coef[p.N + c];
+      bsc[j] = p.bn_coef[2 * p.N + c];
+      bsh[j] = p.bn_coef[3 * p.N + c];
+    }
+#pragma unroll
+    for (int i = 0; i < E_IT; ++i) {
+      const uint32_t m = m0 + (tid + i * 256) / CE;
+      const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0, no scatter
+      const size_t goff = ok ? ((size_t)m * p.ldc + ncol) * sizeof(TOut) : 0;
+      px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
+      if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < E_IT; ++i) {
     const int row = (tid + i * 256) / CE;
@@ -159,7 +183,23 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       for (int j = 0; j < VECO; ++j)
         if (ncol + j < p.N) *reinterpret_cast<TOut*>(dst + j * sizeof(TOut)) = from_float<TOut>(v.get(j));
     }
-    if (p.stats != nullptr) {
+    if constexpr (BNB) {
+      // v holds the values as stored (rounded to TOut): exactly what BatchNorm backward will read back
+      if (ncol + VECO <= p.N) {
+        Vec16<TOut> xb, zb;
+        xb.raw = px[i];
+        zb.raw = pz[i];
+#pragma unroll
+        for (int j = 0; j < VECO; ++j) {
+          float d = v.get(j);
+          const float xv = xb.get(j);
+          if (p.bn_relu == 1 && !(zb.get(j) > 0.f)) d = 0.f;
+          if (p.bn_relu == 2 && !(to_float(from_float<TOut>(bsc[j] * xv + bsh[j])) > 0.f)) d = 0.f;
+          s1[j] += d;
+          s2[j] += d * ((xv - bmu[j]) * bis[j]);
+        }
+      }
+    } else if (p.stats != nullptr) {
 #pragma unroll
       for (int j = 0; j < VECO; ++j) {
         const float f = v.get(j);
@@ -206,7 +246,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
 
 // BM: pixel rows per block, BN: output channels per block, BKB: bytes of K per row per K tile.
 // 256 threads = 2 (pixel) x 2 (channel) waves.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB>
 __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
@@ -394,7 +434,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
     __syncthreads();
   }
 
-  igemm_epilogue<TOut, BM, BN>(p, acc, smem, m0, n0, mt);
+  igemm_epilogue<TOut, BM, BN, BNB>(p, acc, smem, m0, n0, mt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,7 +643,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams
   __builtin_amdgcn_s_barrier();      // every wave is done reading the ring before the epilogue reuses it
   asm volatile("" ::: "memory");
 
-  igemm_epilogue<TOut, BM, BN>(p, acc, smem, m0, n0, mt);
+  igemm_epilogue<TOut, BM, BN, false>(p, acc, smem, m0, n0, mt);
 }
 
 template <typename T, typename TOut, int BM, int BN, int BKB, int S, int MINB>
@@ -624,7 +664,7 @@ void launch_glds(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB = false>
 void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + BN) * LDR;
@@ -637,7 +677,7 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   int lds = (nk > 1 ? 2 : 1) * stage_bytes;
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED>;
+  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED, BNB>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -694,9 +734,23 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
   const bool aligned = p.Cred % (64 / ES) == 0 && fits32;
   const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
   if (!aligned) {
+    if (p.flags & kIgemmBnBwd)
+      throw std::invalid_argument("igemm: fused BN-backward reduction needs a 16-bit, 64-byte aligned problem");
     if (p.N > 64) launch_cfg<T, TOut, 128, 128, 64, 2, false>(p, stream);
     else launch_cfg<T, TOut, 128, 64, 64, 2, false>(p, stream);
     return;
+  }
+  if (p.flags & kIgemmBnBwd) {
+    if constexpr (EXT) {
+      switch (cfg) {
+        case 0: launch_cfg<T, TOut, 128, 128, 128, 2, true, true>(p, stream); return;
+        case 1: launch_cfg<T, TOut, 128, 64, 128, 2, true, true>(p, stream); return;
+        case 2: launch_cfg<T, TOut, 128, 128, 64, 2, true, true>(p, stream); return;
+        case 3: launch_cfg<T, TOut, 128, 64, 64, 2, true, true>(p, stream); return;
+        default: break;
+      }
+    }
+    throw std::invalid_argument("igemm: fused BN-backward reduction needs a 16-bit, 64-byte aligned problem");
   }
   switch (cfg) {
     case 0: launch_cfg<T, TOut, 128, 128, 128, 2, true>(p, stream); return;
@@ -731,6 +785,12 @@ void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t st
   if ((long)p.M >= (1l << 31) || p.ntaps <= 0) throw std::invalid_argument("igemm: bad problem size");
   if (p.stats != nullptr && out_dtype != dtype)
     throw std::invalid_argument("igemm: stats need out dtype == in dtype");
+  if (p.flags & kIgemmBnBwd) {
+    if (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || (p.bn_relu == 1 && p.bn_z == nullptr))
+      throw std::invalid_argument("igemm: fused BN-backward reduction needs stats slab, bn_x, bn_coef (and bn_z)");
+    if (p.N % veco != 0 || p.ldc != p.N)
+      throw std::invalid_argument("igemm: fused BN-backward reduction needs dense rows of whole 16-byte chunks");
+  }
   if (dtype == kF32 && out_dtype == kF32) dispatch_tiles<float, float>(p, stream);
   else if (dtype == kBF16 && out_dtype == kBF16) dispatch_tiles<bf16_t, bf16_t>(p, stream);
   else if (dtype == kBF16 && out_dtype == kF32) dispatch_tiles<bf16_t, float>(p, stream);

@@ -6,7 +6,7 @@
 namespace dpa {
 
 // ------------------------------------------------------------------------------ igemm.hip
-enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2 };
+enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -15,6 +15,13 @@ struct IgemmParams {
   const void* R;       // optional tensor added in the epilogue (same dtype / rows as C): C = conv + R
   const float* bias;   // optional [N]
   float* stats;        // optional per-channel partial (sum, sum^2) slab [tiles_m][2][N]
+  // kIgemmBnBwd (data-gradient launches): the output is the gradient dz of z = [relu](bn(bn_x) [+ res]); the
+  // slab then receives the BatchNorm-backward partials (sum dz_m, sum dz_m * xhat) instead, dz_m = dz masked by
+  // the ReLU (bn_relu 0: none, 1: bn_z > 0, 2: scale*bn_x + shift > 0), so BN backward skips its reduce pass.
+  const void* bn_x;    // BN input, same rows / ldc as C
+  const void* bn_z;    // BN output (bn_relu == 1)
+  const float* bn_coef;  // [4][N]: mean, invstd, scale, shift
+  int bn_relu;
   const int* taps;     // device int32 triples (dy, dx, wtap), ntaps entries
   int M, N, Cred, ntaps;
   int lda, ldb, ldc;
@@ -69,6 +76,7 @@ void bn_finalize_launch(const float* partial, int nparts, int C, double count, c
 void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, int C, float* scale, float* shift,
                            hipStream_t s);
+void bn_set_tuning(int grid_blocks, int unroll);   // tuning hook for the streaming kernels
 void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
                      const float* scale, const float* shift, int relu, hipStream_t s);
 // backward: dy masked by (y > 0) when relu; partial [nblk][2][C] = (sum dy, sum dy*xhat)

@@ -13,6 +13,7 @@ reference's ``model(images)``, ``criterion``, ``loss.backward()`` and
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -65,6 +66,7 @@ _generation = 0          # bumped by optimizers that rewrite parameters through 
 def bump_generation() -> None:
     global _generation
     _generation += 1
+    _pending_bnred.clear()          # never carry a fused BN-backward slab across optimizer steps
 
 
 class _WCache:
@@ -219,15 +221,19 @@ def _conv_out(i, k, s, p):
 
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
-           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None):
+           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None):
     flags = (C().IGEMM_RELU if relu else 0)
+    bn_x = bn_z = bn_coef = bn_relu = 0
+    if bnred is not None:               # (bn input, bn output or None, coef[4][N], relu mode)
+        flags |= C().IGEMM_BN_BWD
+        bn_x, bn_z, bn_coef, bn_relu = bnred[0].data_ptr(), _p(bnred[1]), bnred[2].data_ptr(), bnred[3]
     OHF = OWF = OSY = OSX = OY0 = OX0 = 0
     if scatter is not None:
         flags |= C().IGEMM_SCATTER
         OHF, OWF, OSY, OSX, OY0, OX0 = scatter
     C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
-              _dt(dtype), _dt(out_dtype), _stream())
+              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu)
 
 
 def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
@@ -264,7 +270,8 @@ def _deliver(param, g):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip):
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip, bnsrc=None):
+        x_in = x
         x = x if x.is_contiguous() else x.contiguous()
         NB, IH, IW, Cx = x.shape
         K, Cw, R, S = weight.shape
@@ -290,6 +297,14 @@ class _ConvFn(torch.autograd.Function):
                relu=relu, dtype=x.dtype, out_dtype=x.dtype)
         ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
+        # x is the output of a training-mode BatchNorm: the data-gradient epilogue can produce that BN's
+        # backward partial sums (stride 1: one launch covers every input pixel exactly once)
+        ctx.bnsrc = None
+        if bnsrc is not None:
+            bnsrc.uses += 1
+            if _FUSE_BN_BWD and x is x_in and (sh, sw) == (1, 1) and Cx == Cw and x.dtype != torch.float32 \
+                    and bnsrc.x.shape == x.shape and bnsrc.x.dtype == x.dtype:
+                ctx.bnsrc = bnsrc
         ctx.save_for_backward(x, weight, y if relu else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -314,9 +329,13 @@ class _ConvFn(torch.autograd.Function):
             dy = dym
         dx = dw = db = None
         if dy is None:                      # only the alias was used downstream
-            return dalias, None, None, None, None, None, None, None, None
+            return dalias, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0] and needs_input_grad:
-            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias)
+            bnred = None
+            if ctx.bnsrc is not None and ctx.bnsrc.uses == 1:      # sole consumer of that BN's output
+                src = ctx.bnsrc
+                bnred = (src.x, x if src.mode == 1 else None, src.coef, src.mode)
+            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred)
         elif dalias is not None:
             dx = dalias
         if ctx.needs_input_grad[1]:
@@ -324,10 +343,33 @@ class _ConvFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
             db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv_dgrad(dy, weight, xshape, stride, padding, accum=None):
+# Off by default: measured on MI355X (ResNet-50, batch 256) the fused epilogue costs the data-gradient kernels
+# what the stand-alone reduce kernel took (27.85 vs 27.65 ms/step, profiles/r1_notes.md); kept for smaller
+# batches / future epilogue work.  DPA_FUSE_BN_BWD=1 enables it.
+_FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "0") == "1"
+# data_ptr of a freshly produced data gradient -> (partial slab, data_ptr of the BN input it was reduced
+# against, tensor version).  BatchNorm backward uses the slab only if the gradient it receives is that very
+# tensor, unmodified: autograd sums gradients of a multiply-used tensor either out of place (new data_ptr)
+# or in place (version bump), and both must fall back to the full reduction.
+_pending_bnred: Dict[int, tuple] = {}
+
+
+bn_bwd_counts = {"fused": 0, "reduced": 0}      # how BatchNorm backward obtained its partial sums (tests, tuning)
+
+
+class _BnSrc:
+    """Attached (as ``_dpa_bn``) to the output of a training-mode BatchNorm: what a consuming convolution needs
+    to reduce that BN's backward sums inside its data-gradient epilogue."""
+    __slots__ = ("x", "coef", "mode", "uses")
+
+    def __init__(self, x, coef, mode):
+        self.x, self.coef, self.mode, self.uses = x, coef, mode, 0
+
+
+def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None):
     NB, IH, IW, Cx = xshape
     K, Cw, R, S = weight.shape
     sh, sw = stride
@@ -353,8 +395,16 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None):
             continue
         tt = _tap_table(dy.device, taps)
         scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
-        _igemm(dy, wt, dx, None, None, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
-               SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum)
+        slab = None
+        if bnred is not None and scatter is None and len(classes) == 1 and K % 32 == 0 \
+                and dy.numel() < (1 << 30) and dx.numel() < (1 << 30):
+            rows = C().igemm_stats_rows(NB * SH * SW, Cx, K, len(taps), _dt(dy), _dt(dy))
+            slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
+        _igemm(dy, wt, dx, None, slab, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
+               SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
+               bnred=bnred if slab is not None else None)
+        if slab is not None:
+            _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version)
     return dx
 
 
@@ -405,7 +455,7 @@ def _slice_channels(src: torch.Tensor, dst: torch.Tensor, keep: int) -> None:
 def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad, skip=False):
     grad_sink.note_use(weight, bias)
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
-                                    bool(needs_input_grad), bool(skip))
+                                    bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None))
     out = (y, stats) if want_stats else y
     return (out, alias) if skip else out
 
@@ -489,6 +539,7 @@ class _BNFn(torch.autograd.Function):
         ctx.save_for_backward(x, y if relu_mode == 1 else None, weight, coef, count_dev)
         ctx.bias_ref = bias
         ctx.cfg = (relu_mode, residual is not None, group, count)
+        _BNFn.last = _BnSrc(x, coef, relu_mode)
         return y
 
     @staticmethod
@@ -500,11 +551,17 @@ class _BNFn(torch.autograd.Function):
         M = x.numel() // Cc
         st = _stream()
         dev = x.device
-        nblk = C().bn_partial_rows(M, Cc)
-        part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
-        C().bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), _p(y), M, Cc, _dt(x), coef[0].data_ptr(),
-                          coef[1].data_ptr(), relu, coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(),
-                          nblk, st)
+        fused = _pending_bnred.pop(dy.data_ptr(), None)
+        if fused is not None and fused[1] == x.data_ptr() and fused[2] == dy._version:
+            part = fused[0]         # the producing data-gradient kernel already reduced (sum dy_m, sum dy_m*xhat)
+            bn_bwd_counts["fused"] += 1
+        else:
+            bn_bwd_counts["reduced"] += 1
+            nblk = C().bn_partial_rows(M, Cc)
+            part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
+            C().bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), _p(y), M, Cc, _dt(x), coef[0].data_ptr(),
+                              coef[1].data_ptr(), relu, coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(),
+                              nblk, st)
         # local [dgamma, dbeta]: written straight into the parameters' gradient views when possible
         bias_p = ctx.bias_ref
         sw_, sb_ = grad_sink.sink_of(weight), grad_sink.sink_of(bias_p)
@@ -587,9 +644,14 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
                relu, residual, stats, group):
     if training or running_mean is None:
         grad_sink.note_use(weight, bias)
-        return _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
-                           running_var if training else None, num_batches_tracked if training else None,
-                           float(momentum if momentum is not None else 0.1), float(eps), bool(relu), stats, group)
+        _BNFn.last = None
+        y = _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
+                        running_var if training else None, num_batches_tracked if training else None,
+                        float(momentum if momentum is not None else 0.1), float(eps), bool(relu), stats, group)
+        if _BNFn.last is not None and torch.is_grad_enabled():
+            y._dpa_bn = _BNFn.last      # lets the consuming convolution fuse this BN's backward reduction
+            _BNFn.last = None
+        return y
     return _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), bool(relu))
 
 

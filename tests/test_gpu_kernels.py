@@ -328,3 +328,39 @@ def test_loss_scaler_overflow_skips_step():
         opt.step()
     assert scaler.loss_scale() == 1024.0
     assert abs(p.detach()[0].item() - (1 - 0.1 * 1 - 0.1 * 1.9)) < 1e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("k,with_accum", [(1, False), (3, True)])
+def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
+    """The data-gradient epilogue's fused BatchNorm-backward partial sums equal the stand-alone reduce kernel
+    run on the gradient it stored (same masks, fp32 sums; only the summation order differs)."""
+    from distributed_pytorch_amd.ops import hip_ops
+    C = hip_ops.C()
+    torch.manual_seed(5)
+    N, H, Cin, Cout = 5, 14, 128, 64
+    dt = torch.bfloat16
+    w = (torch.randn(Cout, Cin, k, k, device=DEV) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, H, H, Cout, device=DEV).to(dt)
+    bn_x = (torch.randn(N, H, H, Cin, device=DEV) * 1.5 + 0.3).to(dt)            # the BN input
+    coef = torch.stack([torch.randn(Cin, device=DEV) * 0.1, torch.rand(Cin, device=DEV) + 0.5,
+                        torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.2]).contiguous()
+    z = torch.randn(N, H, H, Cin, device=DEV).to(dt)                              # BN output (mask source, mode 1)
+    accum = torch.randn(N, H, H, Cin, device=DEV).to(dt) if with_accum else None
+    p = k // 2
+    hip_ops._pending_bnred.clear()
+    dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum,
+                            bnred=(bn_x, z if mode == 1 else None, coef, mode))
+    slab, xptr, _ = hip_ops._pending_bnred.pop(dx.data_ptr())
+    assert xptr == bn_x.data_ptr()
+    ref_dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum)
+    assert torch.equal(dx, ref_dx)                                                # the gradient itself is untouched
+    M = N * H * H
+    nblk = C.bn_partial_rows(M, Cin)
+    part = torch.empty(nblk, 2, Cin, device=DEV)
+    C.bn_bwd_reduce(dx.data_ptr(), bn_x.data_ptr(), z.data_ptr() if mode == 1 else 0, M, Cin, hip_ops._dt(dx),
+                    coef[0].data_ptr(), coef[1].data_ptr(), mode, coef[2].data_ptr(), coef[3].data_ptr(),
+                    part.data_ptr(), nblk, torch.cuda.current_stream().cuda_stream)
+    got, want = slab.sum(0), part.sum(0)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 1e-4 * scale, (got - want).abs().max().item() / scale
