@@ -330,6 +330,20 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if dy is None:                      # only the alias was used downstream
             return dalias, None, None, None, None, None, None, None, None, None
+        wgrad_done = False
+        _sk = grad_sink.sink_of(weight)
+        if ctx.needs_input_grad[1] and _WGRAD_STREAM and dy.is_cuda and (_sk is None or _sk.on_ready is None):
+            # weight gradient on the side stream, enqueued BEFORE the data gradient so the two run concurrently
+            # (the dgrad -> BN chain is full of launches that leave most of the chip idle)
+            side = side_stream(dy.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
+            dy.record_stream(side)
+            x.record_stream(side)
+            if dw is not None:              # handed back to autograd on the main stream
+                torch.cuda.current_stream().wait_stream(side)
+            wgrad_done = True
         if ctx.needs_input_grad[0] and needs_input_grad:
             bnred = None
             if ctx.bnsrc is not None and ctx.bnsrc.uses == 1:      # sole consumer of that BN's output
@@ -338,7 +352,7 @@ class _ConvFn(torch.autograd.Function):
             dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred)
         elif dalias is not None:
             dx = dalias
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not wgrad_done:
             dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
@@ -349,6 +363,25 @@ class _ConvFn(torch.autograd.Function):
 # Off by default: measured on MI355X (ResNet-50, batch 256) the fused epilogue costs the data-gradient kernels
 # what the stand-alone reduce kernel took (27.85 vs 27.65 ms/step, profiles/r1_notes.md); kept for smaller
 # batches / future epilogue work.  DPA_FUSE_BN_BWD=1 enables it.
+# Side stream for weight gradients (single-process runs; see _ConvFn.backward).  join_side_stream() orders the
+# current stream after everything enqueued there -- called before the optimizer reads the gradients.
+_WGRAD_STREAM = os.environ.get("DPA_WGRAD_STREAM", "0") == "1"
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device)
+        _side_streams[device.index] = s
+    return s
+
+
+def join_side_stream() -> None:
+    for s in _side_streams.values():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "0") == "1"
 # data_ptr of a freshly produced data gradient -> (partial slab, data_ptr of the BN input it was reduced
 # against, tensor version).  BatchNorm backward uses the slab only if the gradient it receives is that very

@@ -110,6 +110,9 @@ class FusedSGD(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         scaler, self._scaler = self._scaler, None
+        from .ops import hip_ops as _hip_ops
+
+        _hip_ops.join_side_stream()
         for arena in self._arenas():
             arena.finish_step()
         from .ops import functional as _F
