@@ -114,6 +114,24 @@ PYBIND11_MODULE(_C, m) {
                           eps, C, ptr<float>(scale), ptr<float>(shift), st(s));
   });
   m.def("bn_set_tuning", &bn_set_tuning);
+  m.def("bn_fold_chunks", &bn_fold_chunks);
+  m.def("bn_fold_finalize", [](uintptr_t partial, int nparts, int C, uintptr_t tmp, uintptr_t counter, double count,
+                               uintptr_t gamma, uintptr_t beta, float eps, float momentum, uintptr_t rm, uintptr_t rv,
+                               uintptr_t nbt, uintptr_t mean, uintptr_t invstd, uintptr_t scale, uintptr_t shift,
+                               uintptr_t s) {
+    bn_fold_finalize_launch(ptr<const float>(partial), nparts, C, ptr<double>(tmp), ptr<int>(counter), count,
+                            ptr<const float>(gamma), ptr<const float>(beta), eps, momentum, ptr<float>(rm),
+                            ptr<float>(rv), ptr<long>(nbt), ptr<float>(mean), ptr<float>(invstd), ptr<float>(scale),
+                            ptr<float>(shift), st(s));
+  });
+  m.def("bn_bwd_fold_finalize", [](uintptr_t partial, int nparts, int C, uintptr_t tmp, uintptr_t counter,
+                                   double count, uintptr_t gamma, uintptr_t mean, uintptr_t invstd, uintptr_t scale,
+                                   uintptr_t shift, uintptr_t dgamma, uintptr_t dbeta, uintptr_t coef, uintptr_t s) {
+    bn_bwd_fold_finalize_launch(ptr<const float>(partial), nparts, C, ptr<double>(tmp), ptr<int>(counter), count,
+                                ptr<const float>(gamma), ptr<const float>(mean), ptr<const float>(invstd),
+                                ptr<const float>(scale), ptr<const float>(shift), ptr<float>(dgamma),
+                                ptr<float>(dbeta), ptr<float>(coef), st(s));
+  });
   m.def("bn_apply", [](uintptr_t x, uintptr_t res, uintptr_t y, long M, int C, int dtype, uintptr_t scale,
                        uintptr_t shift, int relu, uintptr_t s) {
     bn_apply_launch(ptr<const void>(x), ptr<const void>(res), ptr<void>(y), M, C, dtype, ptr<const float>(scale),

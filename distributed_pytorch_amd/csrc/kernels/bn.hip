@@ -206,6 +206,122 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch: fold a long partial slab [nparts][2][C] AND finalize.  Workgroup (g, j) folds its chunk of parts
+// for 64 channels (4 part lanes x 64 channel lanes, fixed order) into tmp[j][2][C]; the LAST workgroup of a
+// column group to finish (agent-scope release + ticket, acquire by the last arriver -- cdna guide "in-launch
+// split-K reduction") sums the nchunk rows in index order and writes the coefficients.  The ticket counter is
+// returned to zero by that workgroup.  Replaces fold_partials + bn_finalize (forward) and fold_partials +
+// bn_bwd_finalize_fused (backward): 2 of the 4 tiny launches per BatchNorm layer and direction.
+// MODE 0: forward statistics -> mean, invstd, scale, shift (+ running stats).  MODE 1: backward sums ->
+// dgamma, dbeta, apply coefficients [5][C].
+struct BnFinalizeArgs {
+  const float* partial; int nparts, C, chunk, nchunk;
+  double* tmp; int* counter;
+  double count; float eps, momentum;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; long* num_batches_tracked;
+  float* mean; float* invstd; float* scale; float* shift;          // MODE 0 outputs / MODE 1 inputs
+  float* dgamma; float* dbeta; float* coef;                          // MODE 1 outputs
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeArgs a) {
+  // sums are carried in double from the first add: var = E[x^2] - mean^2 cancels badly in float when the
+  // slab is long, and this kernel is latency bound, not ALU bound
+  __shared__ double red[2][4][64];
+  __shared__ int is_last;
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int g = blockIdx.x, j = blockIdx.y;
+  const int c = g * 64 + cl, C = a.C;
+  const int p0 = j * a.chunk, p1 = min(a.nparts, p0 + a.chunk);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    int k = p0 + pl;
+    for (; k + 12 < p1; k += 16) {          // 4 independent row pairs in flight per lane
+      const float a0 = a.partial[((size_t)k * 2 + 0) * C + c], b0 = a.partial[((size_t)k * 2 + 1) * C + c];
+      const float a1 = a.partial[((size_t)(k + 4) * 2 + 0) * C + c], b1 = a.partial[((size_t)(k + 4) * 2 + 1) * C + c];
+      const float a2 = a.partial[((size_t)(k + 8) * 2 + 0) * C + c], b2 = a.partial[((size_t)(k + 8) * 2 + 1) * C + c];
+      const float a3 = a.partial[((size_t)(k + 12) * 2 + 0) * C + c], b3 = a.partial[((size_t)(k + 12) * 2 + 1) * C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; k < p1; k += 4) {
+      s1 += (double)a.partial[((size_t)k * 2 + 0) * C + c];
+      s2 += (double)a.partial[((size_t)k * 2 + 1) * C + c];
+    }
+  }
+  red[0][pl][cl] = s1;
+  red[1][pl][cl] = s2;
+  __syncthreads();
+  if (a.nchunk > 1) {
+    if (pl == 0 && c < C) {
+      a.tmp[((size_t)j * 2 + 0) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+      a.tmp[((size_t)j * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(&a.counter[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = ticket == a.nchunk - 1;
+      if (is_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&a.counter[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+    }
+    __syncthreads();
+    if (!is_last) return;
+  }
+  if (pl != 0 || c >= C) return;
+  double t1, t2;
+  if (a.nchunk > 1) {
+    t1 = t2 = 0.0;
+    for (int k = 0; k < a.nchunk; ++k) {
+      t1 += a.tmp[((size_t)k * 2 + 0) * C + c];
+      t2 += a.tmp[((size_t)k * 2 + 1) * C + c];
+    }
+  } else {
+    t1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    t2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  }
+  if (MODE == 0) {
+    if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
+    const double m = t1 / a.count;
+    double var = t2 / a.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)a.eps));
+    a.mean[c] = (float)m;
+    a.invstd[c] = is;
+    const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+    a.scale[c] = gm * is;
+    a.shift[c] = bt - (float)m * gm * is;
+    if (a.running_mean != nullptr) {
+      const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+  } else {
+    const float db = (float)t1, dg = (float)t2;
+    a.dbeta[c] = db;
+    a.dgamma[c] = dg;
+    if (a.coef != nullptr) {
+      const float inv_count = (float)(1.0 / a.count);
+      const float is = a.invstd[c], gm = a.gamma ? a.gamma[c] : 1.f;
+      const float A = gm * is;
+      const float B = -A * is * dg * inv_count;
+      a.coef[c] = A;
+      a.coef[C + c] = B;
+      a.coef[2 * C + c] = -A * db * inv_count - B * a.mean[c];
+      a.coef[3 * C + c] = a.scale ? a.scale[c] : 0.f;
+      a.coef[4 * C + c] = a.shift ? a.shift[c] : 0.f;
+    }
+  }
+}
+
+
 // Per-channel coefficient vectors are loop-invariant for a thread whenever the grid stride is a
 // multiple of the chunk-column count (always true for power-of-two channel counts): they are then
 // loaded ONCE into registers instead of per element.
@@ -515,6 +631,49 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
                                                coef, relu));
   DPA_CHECK_HIP(hipGetLastError());
+}
+
+// Rows of the scratch slab bn_fold_finalize needs for `nparts` partial rows (1 = no scratch pass).
+int bn_fold_chunks(int nparts) {
+  if (nparts <= 64) return 1;
+  int n = (nparts + 31) / 32;          // >= 32 rows per workgroup
+  return n > 32 ? 32 : n;
+}
+
+static void fold_finalize_launch(int mode, BnFinalizeArgs a, hipStream_t s) {
+  if (a.nparts <= 0 || a.C <= 0) return;
+  a.nchunk = bn_fold_chunks(a.nparts);
+  a.chunk = (a.nparts + a.nchunk - 1) / a.nchunk;
+  if (a.nchunk > 1 && (a.tmp == nullptr || a.counter == nullptr))
+    throw std::invalid_argument("bn_fold_finalize: scratch slab and ticket counters required");
+  if (ceil_div(a.C, 64) > 64) throw std::invalid_argument("bn_fold_finalize: more than 4096 channels");
+  dim3 grid(ceil_div(a.C, 64), a.nchunk);
+  if (mode == 0) hipLaunchKernelGGL(bn_fold_finalize_kernel<0>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(bn_fold_finalize_kernel<1>, grid, dim3(256), 0, s, a);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_fold_finalize_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
+                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, long* num_batches_tracked, float* mean, float* invstd, float* scale,
+                             float* shift, hipStream_t s) {
+  BnFinalizeArgs a{};
+  a.partial = partial; a.nparts = nparts; a.C = C; a.tmp = tmp; a.counter = counter; a.count = count;
+  a.eps = eps; a.momentum = momentum; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean;
+  a.running_var = running_var; a.num_batches_tracked = num_batches_tracked;
+  a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift;
+  fold_finalize_launch(0, a, s);
+}
+
+void bn_bwd_fold_finalize_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
+                                 const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                 const float* shift, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
+  BnFinalizeArgs a{};
+  a.partial = partial; a.nparts = nparts; a.C = C; a.tmp = tmp; a.counter = counter; a.count = count;
+  a.gamma = gamma; a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);
+  a.scale = const_cast<float*>(scale); a.shift = const_cast<float*>(shift);
+  a.dgamma = dgamma; a.dbeta = dbeta; a.coef = coef;
+  fold_finalize_launch(1, a, s);
 }
 
 void bn_set_tuning(int grid_blocks, int unroll) {

@@ -76,6 +76,16 @@ void bn_finalize_launch(const float* partial, int nparts, int C, double count, c
 void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, int C, float* scale, float* shift,
                            hipStream_t s);
+// fold + finalize in one launch (last-arriver pattern); tmp: [bn_fold_chunks(nparts)][2][C] doubles, counter: >= 64
+// zero-initialised ints that the kernel leaves zeroed (one launch at a time per counter array)
+int bn_fold_chunks(int nparts);
+void bn_fold_finalize_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
+                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, long* num_batches_tracked, float* mean, float* invstd, float* scale,
+                             float* shift, hipStream_t s);
+void bn_bwd_fold_finalize_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
+                                 const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                 const float* shift, float* dgamma, float* dbeta, float* coef, hipStream_t s);
 void bn_set_tuning(int grid_blocks, int unroll);   // tuning hook for the streaming kernels
 void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
                      const float* scale, const float* shift, int relu, hipStream_t s);

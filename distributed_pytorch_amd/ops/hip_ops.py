@@ -510,6 +510,21 @@ def _fold(part: torch.Tensor, C_: int, limit: int = 64) -> torch.Tensor:
     return out
 
 
+_bn_tickets: Dict[int, torch.Tensor] = {}
+
+
+def _bn_scratch(nparts: int, C_: int, device):
+    """(tmp slab or None, ticket counters) for the one-launch fold + finalize kernels.  The counters are zeroed
+    once; every launch leaves them zeroed.  BatchNorm kernels of one device run on one stream."""
+    t = _bn_tickets.get(device.index)
+    if t is None:
+        t = torch.zeros(64, dtype=torch.int32, device=device)
+        _bn_tickets[device.index] = t
+    n = C().bn_fold_chunks(nparts)
+    tmp = torch.empty((n, 2, C_), dtype=torch.float64, device=device) if n > 1 else None
+    return tmp, t
+
+
 _FORCE_SYNC_PATH = False     # tests: take the SyncBN code path (all-reduce of a 1-rank group) on one GPU
 
 
@@ -543,11 +558,13 @@ class _BNFn(torch.autograd.Function):
             nblk = C().bn_partial_rows(M, Cc)
             stats = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
             C().bn_stats(x.data_ptr(), M, Cc, _dt(x), stats.data_ptr(), nblk, st)
-        part = _fold(stats, Cc)
         count = float(M)
         count_dev = None
         world = _group_size(group)
+        g32, b32 = _f32(weight.detach()), _f32(bias.detach())
+        coef = torch.empty((4, Cc), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
         if world > 1:
+            part = _fold(stats, Cc)
             # SyncBN: all-reduce [sum(C), sumsq(C), rows] -- one small message per layer
             packed = torch.empty(2 * Cc + 1, dtype=torch.float32, device=dev)
             C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, packed[Cc:2 * Cc].data_ptr(),
@@ -556,11 +573,16 @@ class _BNFn(torch.autograd.Function):
             _all_reduce_sum(packed, group)
             count_dev = packed[2 * Cc:]
             part = packed[:2 * Cc].view(1, 2, Cc)
-        g32, b32 = _f32(weight.detach()), _f32(bias.detach())
-        coef = torch.empty((4, Cc), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
-        C().bn_finalize(part.data_ptr(), part.shape[0], Cc, count, _p(count_dev), g32.data_ptr(), b32.data_ptr(),
-                        eps, momentum, _p(running_mean), _p(running_var), _p(nbt), coef[0].data_ptr(),
-                        coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+            C().bn_finalize(part.data_ptr(), part.shape[0], Cc, count, _p(count_dev), g32.data_ptr(),
+                            b32.data_ptr(), eps, momentum, _p(running_mean), _p(running_var), _p(nbt),
+                            coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+        else:
+            # one launch folds the per-tile partial slab and writes mean / invstd / scale / shift + running stats
+            tmp, tickets = _bn_scratch(stats.shape[0], Cc, dev)
+            C().bn_fold_finalize(stats.data_ptr(), stats.shape[0], Cc, _p(tmp), tickets.data_ptr(), count,
+                                 g32.data_ptr(), b32.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
+                                 _p(nbt), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                                 coef[3].data_ptr(), st)
         if residual is not None and not residual.is_contiguous():
             residual = residual.contiguous()
         y = torch.empty_like(x)
@@ -608,11 +630,17 @@ class _BNFn(torch.autograd.Function):
         g32 = _f32(weight.detach())
         wk = torch.empty((5, Cc), dtype=torch.float32, device=dev)
         sync = _group_size(group) > 1
-        # fold the partial slab (wide first stage when it is long) and, non-sync, emit the apply coefficients
-        part = _fold(part, Cc)
-        C().bn_bwd_finalize_fused(part.data_ptr(), part.shape[0], Cc, dg_t.data_ptr(), db_t.data_ptr(),
-                                  coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), count,
-                                  0 if sync else wk.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+        if not sync:
+            # one launch: fold the partial slab, dgamma / dbeta and the apply coefficients
+            tmp, tickets = _bn_scratch(part.shape[0], Cc, dev)
+            C().bn_bwd_fold_finalize(part.data_ptr(), part.shape[0], Cc, _p(tmp), tickets.data_ptr(), count,
+                                     g32.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                                     coef[3].data_ptr(), dg_t.data_ptr(), db_t.data_ptr(), wk.data_ptr(), st)
+        else:
+            part = _fold(part, Cc)
+            C().bn_bwd_finalize_fused(part.data_ptr(), part.shape[0], Cc, dg_t.data_ptr(), db_t.data_ptr(),
+                                      coef[0].data_ptr(), coef[1].data_ptr(), g32.data_ptr(), count,
+                                      0, coef[2].data_ptr(), coef[3].data_ptr(), st)
         if sync:
             gs = torch.stack([dg_t, db_t])
             _all_reduce_sum(gs, group)
