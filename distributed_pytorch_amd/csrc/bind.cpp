@@ -229,6 +229,9 @@ PYBIND11_MODULE(_C, m) {
   m.def("transpose_ktc", [](uintptr_t w, uintptr_t wt, int K, int T, int C, int in_dtype, int out_dtype, uintptr_t s) {
     transpose_ktc_launch(ptr<const void>(w), ptr<void>(wt), K, T, C, in_dtype, out_dtype, st(s));
   });
+  m.def("copy_rows", [](uintptr_t src, long ld_src, uintptr_t dst, long ld_dst, long rows, long row_bytes, uintptr_t s) {
+    copy_rows_launch(ptr<const void>(src), ld_src, ptr<void>(dst), ld_dst, rows, row_bytes, st(s));
+  });
   m.def("axpby", [](uintptr_t x, int x_dtype, uintptr_t y, long n, float alpha, float beta, uintptr_t s) {
     axpby_launch(ptr<const void>(x), x_dtype, ptr<float>(y), n, alpha, beta, st(s));
   });

@@ -175,6 +175,18 @@ __global__ __launch_bounds__(256) void axpby_kernel(const TX* __restrict__ x, fl
   }
 }
 
+// dst[r][0..cols) = src[r][0..cols) for row-strided 2-D views, 16 bytes per lane (channel concat / split in NHWC)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint4* __restrict__ src, long ld_src, uint4* __restrict__ dst,
+                                                        long ld_dst, long rows, int chunks) {
+  const long total = rows * chunks;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / chunks;
+    const int c = (int)(i - r * chunks);
+    dst[r * ld_dst + c] = src[r * ld_src + c];
+  }
+}
+
 #define DPA_DISPATCH_2(di, dout, ...)                                                        \
   DPA_DISPATCH_DTYPE(di, { using TI = T; DPA_DISPATCH_DTYPE(dout, { using TO = T; __VA_ARGS__; }) })
 
@@ -249,6 +261,17 @@ void axpby_launch(const void* x, int x_dtype, float* y, long n, float alpha, flo
   if (n <= 0) return;
   DPA_DISPATCH_DTYPE(x_dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, y, n,
                                                  alpha, beta));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void copy_rows_launch(const void* src, long ld_src_bytes, void* dst, long ld_dst_bytes, long rows, long row_bytes,
+                      hipStream_t s) {
+  if (rows <= 0 || row_bytes <= 0) return;
+  if (row_bytes % 16 || ld_src_bytes % 16 || ld_dst_bytes % 16 || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16))
+    throw std::invalid_argument("copy_rows: rows, strides and bases must be multiples of 16 bytes");
+  const int chunks = (int)(row_bytes / 16);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * chunks)), dim3(256), 0, s, (const uint4*)src,
+                     ld_src_bytes / 16, (uint4*)dst, ld_dst_bytes / 16, rows, chunks);
   DPA_CHECK_HIP(hipGetLastError());
 }
 

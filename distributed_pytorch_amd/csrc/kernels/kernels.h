@@ -146,6 +146,9 @@ void transpose_ktc_launch(const void* w, void* wt, int K, int T, int C, int in_d
                           hipStream_t s);
 void axpby_launch(const void* x, int x_dtype, float* y, long n, float alpha, float beta, hipStream_t s);
 void fill_launch(void* p, long nbytes, int value, hipStream_t s);
+// strided 2-D copy in 16-byte chunks: channel concat / split of NHWC activations
+void copy_rows_launch(const void* src, long ld_src_bytes, void* dst, long ld_dst_bytes, long rows, long row_bytes,
+                      hipStream_t s);
 
 // ------------------------------------------------------------------------------ optim.hip
 struct SgdTensor {   // one entry per parameter tensor (device table)

@@ -97,12 +97,21 @@ class ReLU(nn.Module):
 
 
 class MaxPool2d(nn.Module):
-    def __init__(self, kernel_size, stride=None, padding=0):
+    def __init__(self, kernel_size, stride=None, padding=0, ceil_mode: bool = False):
         super().__init__()
-        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.kernel_size, self.stride, self.padding, self.ceil_mode = kernel_size, stride, padding, ceil_mode
 
     def forward(self, x):
-        return F.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+        return F.max_pool2d(x, self.kernel_size, self.stride, self.padding, self.ceil_mode)
+
+
+class AvgPool2d(nn.Module):
+    def __init__(self, kernel_size, stride=None):
+        super().__init__()
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x):
+        return F.avg_pool2d(x, self.kernel_size, self.stride)
 
 
 class AdaptiveAvgPool2d(nn.Module):

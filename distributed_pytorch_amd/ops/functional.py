@@ -111,11 +111,32 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
 
 
 # ----------------------------------------------------------------------------- pooling
-def max_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0) -> torch.Tensor:
+def max_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, ceil_mode: bool = False) -> torch.Tensor:
     k, s, p = _pair(kernel_size), _pair(stride if stride is not None else kernel_size), _pair(padding)
     if _on_gpu(x):
-        return _hip().max_pool2d(x, k, s, p)
-    return TF.max_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
+        return _hip().max_pool2d(x, k, s, p, ceil_mode)
+    return TF.max_pool2d(x.permute(0, 3, 1, 2), k, s, p, ceil_mode=ceil_mode).permute(0, 2, 3, 1).contiguous()
+
+
+def avg_pool2d(x: torch.Tensor, kernel_size, stride=None) -> torch.Tensor:
+    """Non-overlapping average pooling (DenseNet transitions: 2x2 stride 2 on even extents) -- on the GPU this
+    is the adaptive average-pool kernel with the output extent H/k."""
+    k, s = _pair(kernel_size), _pair(stride if stride is not None else kernel_size)
+    if k != s or x.shape[1] % k[0] or x.shape[2] % k[1]:
+        if _on_gpu(x):
+            raise NotImplementedError("avg_pool2d on the GPU supports kernel == stride dividing the input extent")
+        return TF.avg_pool2d(x.permute(0, 3, 1, 2), k, s).permute(0, 2, 3, 1).contiguous()
+    return adaptive_avg_pool2d(x, (x.shape[1] // k[0], x.shape[2] // k[1]))
+
+
+def cat_channels(xs) -> torch.Tensor:
+    """Concatenate NHWC tensors along the channel axis."""
+    xs = list(xs)
+    if len(xs) == 1:
+        return xs[0]
+    if _on_gpu(xs[0]):
+        return _hip().cat_channels(xs)
+    return torch.cat(xs, dim=-1)
 
 
 def adaptive_avg_pool2d(x: torch.Tensor, output_size) -> torch.Tensor:

@@ -721,10 +721,10 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
 # ------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, s, p):
+    def forward(ctx, x, k, s, p, ceil_mode=False):
         x = x if x.is_contiguous() else x.contiguous()
         NB, IH, IW, Cc = x.shape
-        OH, OW = _conv_out(IH, k[0], s[0], p[0]), _conv_out(IW, k[1], s[1], p[1])
+        OH, OW = _pool_out(IH, k[0], s[0], p[0], ceil_mode), _pool_out(IW, k[1], s[1], p[1], ceil_mode)
         y = torch.empty((NB, OH, OW, Cc), dtype=x.dtype, device=x.device)
         if k[0] * k[1] > 250:
             raise ValueError("max_pool2d: window too large")
@@ -744,11 +744,66 @@ class _MaxPoolFn(torch.autograd.Function):
         dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device)
         C().maxpool_bwd(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
                         p[0], p[1], _dt(dy), _stream())
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def max_pool2d(x, k, s, p):
-    return _MaxPoolFn.apply(x, tuple(k), tuple(s), tuple(p))
+def max_pool2d(x, k, s, p, ceil_mode=False):
+    return _MaxPoolFn.apply(x, tuple(k), tuple(s), tuple(p), bool(ceil_mode))
+
+
+def _pool_out(i, k, s, p, ceil_mode):
+    """torch's pooling output extent; with ceil_mode the last window may hang over the right / bottom edge but
+    must start inside the (left-padded) input."""
+    if not ceil_mode:
+        return (i + 2 * p - k) // s + 1
+    o = -(-(i + 2 * p - k) // s) + 1
+    if (o - 1) * s >= i + p:
+        o -= 1
+    return o
+
+
+class _CatFn(torch.autograd.Function):
+    """Channel concat of NHWC tensors (SqueezeNet fire modules, DenseNet feature reuse): one strided copy kernel
+    per source; backward splits the gradient with the same kernel."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [t if t.is_contiguous() else t.contiguous() for t in xs]
+        lead = xs[0].shape[:-1]
+        rows = xs[0].numel() // xs[0].shape[-1]
+        cs = [t.shape[-1] for t in xs]
+        es = xs[0].element_size()
+        if any(t.shape[:-1] != lead or t.dtype != xs[0].dtype for t in xs) or any((c * es) % 16 for c in cs):
+            raise ValueError("cat_channels: inputs must share shape/dtype and have 16-byte multiples of channels")
+        tot = sum(cs)
+        out = torch.empty(tuple(lead) + (tot,), dtype=xs[0].dtype, device=xs[0].device)
+        off = 0
+        for t, c in zip(xs, cs):
+            C().copy_rows(t.data_ptr(), c * es, out.data_ptr() + off * es, tot * es, rows, c * es, _stream())
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        cs, es = ctx.cs, dy.element_size()
+        tot = sum(cs)
+        rows = dy.numel() // tot
+        outs, off = [], 0
+        for i, c in enumerate(cs):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty(dy.shape[:-1] + (c,), dtype=dy.dtype, device=dy.device)
+                C().copy_rows(dy.data_ptr() + off * es, tot * es, g.data_ptr(), c * es, rows, c * es, _stream())
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _CatFn.apply(*xs)
 
 
 class _AvgPoolFn(torch.autograd.Function):

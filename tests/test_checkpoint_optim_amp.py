@@ -14,7 +14,8 @@ def _tiny():
 
 
 def test_param_counts_and_torchvision_key_names():
-    want = {"resnet18": 11689512, "resnet50": 25557032, "alexnet": 61100840, "vgg16": 138357544}
+    want = {"resnet18": 11689512, "resnet50": 25557032, "alexnet": 61100840, "vgg16": 138357544,
+            "squeezenet1_0": 1248424, "squeezenet1_1": 1235496, "densenet121": 7978856, "densenet169": 14149480}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch
@@ -26,6 +27,13 @@ def test_param_counts_and_torchvision_key_names():
     assert sd["conv1.weight"].shape == (64, 3, 7, 7)
     va = models.create_model("vgg16").state_dict()
     assert va["features.0.weight"].shape == (64, 3, 3, 3) and va["classifier.0.weight"].shape == (4096, 25088)
+    dn = models.create_model("densenet121").state_dict()
+    for k in ("features.conv0.weight", "features.denseblock1.denselayer1.norm1.running_mean",
+              "features.denseblock4.denselayer16.conv2.weight", "features.transition2.conv.weight",
+              "features.norm5.bias", "classifier.weight"):
+        assert k in dn, k
+    sq = models.create_model("squeezenet1_1").state_dict()
+    assert sq["features.3.squeeze.weight"].shape == (16, 64, 1, 1) and sq["classifier.1.weight"].shape == (1000, 512, 1, 1)
     al = models.create_model("alexnet").state_dict()
     assert al["features.0.weight"].shape == (64, 3, 11, 11) and al["classifier.1.weight"].shape == (4096, 9216)
 

@@ -364,3 +364,30 @@ def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     got, want = slab.sum(0), part.sum(0)
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 1e-4 * scale, (got - want).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cat_channels_ceil_maxpool_avgpool(dtype):
+    torch.manual_seed(11)
+    a = torch.randn(3, 9, 7, 64, device=DEV).to(dtype).requires_grad_(True)
+    b = torch.randn(3, 9, 7, 32, device=DEV).to(dtype).requires_grad_(True)
+    y = F.cat_channels([a, b])
+    assert torch.equal(y, torch.cat([a, b], -1))
+    g = torch.randn_like(y.float()).to(dtype)
+    y.backward(g)
+    assert torch.equal(a.grad, g[..., :64]) and torch.equal(b.grad, g[..., 64:])
+    # ceil_mode max pooling (SqueezeNet): 13 -> 6, 14 -> 7 (the last window hangs over the edge)
+    for H in (13, 14, 55):
+        x = torch.randn(2, H, H, 16, device=DEV).to(dtype).requires_grad_(True)
+        yp = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+        xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = TF.max_pool2d(xr, 3, 2, 0, ceil_mode=True)
+        assert yp.shape[1:3] == yr.shape[2:]
+        _close(yp.permute(0, 3, 1, 2), yr, dtype, what="maxpool ceil fwd")
+        gy = torch.randn_like(yr)
+        yp.backward(gy.permute(0, 2, 3, 1).to(dtype))
+        yr.backward(gy.to(dtype).float())
+        _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype, what="maxpool ceil bwd")
+    x = torch.randn(2, 8, 12, 32, device=DEV).to(dtype)
+    _close(F.avg_pool2d(x, 2, 2).permute(0, 3, 1, 2), TF.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2), dtype,
+           what="avgpool 2x2")
