@@ -114,6 +114,7 @@ PYBIND11_MODULE(_C, m) {
                           eps, C, ptr<float>(scale), ptr<float>(shift), st(s));
   });
   m.def("bn_set_tuning", &bn_set_tuning);
+  m.def("bn_set_reverse", &bn_set_reverse);
   m.def("bn_fold_chunks", &bn_fold_chunks);
   m.def("bn_fold_finalize", [](uintptr_t partial, int nparts, int C, uintptr_t tmp, uintptr_t counter, double count,
                                uintptr_t gamma, uintptr_t beta, float eps, float momentum, uintptr_t rm, uintptr_t rv,

@@ -336,21 +336,26 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, f
 
 int g_bn_grid = 256 * 8;     // tuning hooks (bench/bn_layers.py): workgroups of the streaming kernels, unroll
 int g_bn_unroll = 1;
+int g_bn_reverse = 0;        // 1: the apply kernels walk their tensors from the END (what the producer wrote last
+                             // is still in the Infinity Cache / L2)
 
 template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, long nchunks, int cc,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int relu) {
+                                                       const float* __restrict__ shift, int relu, int rev) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const long stride = (long)gridDim.x * blockDim.x;
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float scv[VEC], shv[VEC];
-  int c0 = (int)(i % cc) * VEC;
+  // rev: chunk q = nchunks-1-i, i.e. the tensor is walked from its end (the rows the producing kernel wrote
+  // last are the ones still cached); q % cc is again constant per thread when the stride is a multiple of cc
+  int c0 = (int)((rev ? nchunks - 1 - i : i) % cc) * VEC;
+  if (i >= nchunks) return;
   load_coef<VEC>(scale, c0, scv);
   load_coef<VEC>(shift, c0, shv);
-  if (U > 1 && fixed) {
+  if (U > 1 && fixed && !rev) {
     // U chunks per thread per trip, all loads issued before the first use: more bytes in flight per wave
     for (; i + (U - 1) * stride < nchunks; i += U * stride) {
       Vec16<T> vx[U], vr[U];
@@ -375,14 +380,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
   }
   for (; i < nchunks; i += stride) {
+    const long q = rev ? nchunks - 1 - i : i;
     if (!fixed) {
-      c0 = (int)(i % cc) * VEC;
+      c0 = (int)(q % cc) * VEC;
       load_coef<VEC>(scale, c0, scv);
       load_coef<VEC>(shift, c0, shv);
     }
     Vec16<T> vx, vr, vo;
-    vx.load(x + i * VEC);
-    if (res != nullptr) vr.load(res + i * VEC);
+    vx.load(x + q * VEC);
+    if (res != nullptr) vr.load(res + q * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float v = vx.get(j) * scv[j] + shv[j];
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       if (relu) v = fmaxf(v, 0.f);
       vo.set(j, v);
     }
-    vo.store(y + i * VEC);
+    vo.store(y + q * VEC);
   }
 }
 
@@ -454,21 +460,23 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, T* __restrict__ dx,
                                                            T* __restrict__ dres, long nchunks, int cc, int C,
-                                                           const float* __restrict__ coef, int relu) {
+                                                           const float* __restrict__ coef, int relu, int rev) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const long stride = (long)gridDim.x * blockDim.x;
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float ca[VEC], cb[VEC], ck[VEC], sc[VEC], sh[VEC];
-  int c0 = (int)(i % cc) * VEC;
+  if (i >= nchunks) return;
+  int c0 = (int)((rev ? nchunks - 1 - i : i) % cc) * VEC;
   load_coef<VEC>(coef, c0, ca);
   load_coef<VEC>(coef + C, c0, cb);
   load_coef<VEC>(coef + 2 * C, c0, ck);
   load_coef<VEC>(coef + 3 * C, c0, sc);
   load_coef<VEC>(coef + 4 * C, c0, sh);
   for (; i < nchunks; i += stride) {
+    const long q = rev ? nchunks - 1 - i : i;
     if (!fixed) {
-      c0 = (int)(i % cc) * VEC;
+      c0 = (int)(q % cc) * VEC;
       load_coef<VEC>(coef, c0, ca);
       load_coef<VEC>(coef + C, c0, cb);
       load_coef<VEC>(coef + 2 * C, c0, ck);
@@ -476,9 +484,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       load_coef<VEC>(coef + 4 * C, c0, sh);
     }
     Vec16<T> vd, vx, vy, vo, vr;
-    vd.load(dy + i * VEC);
-    vx.load(x + i * VEC);
-    if (relu == 1) vy.load(y + i * VEC);
+    vd.load(dy + q * VEC);
+    vx.load(x + q * VEC);
+    if (relu == 1) vy.load(y + q * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float d = vd.get(j);
@@ -488,8 +496,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
       vr.set(j, d);
     }
-    vo.store(dx + i * VEC);
-    if (dres != nullptr) vr.store(dres + i * VEC);
+    vo.store(dx + q * VEC);
+    if (dres != nullptr) vr.store(dres + q * VEC);
   }
 }
 
@@ -592,13 +600,13 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const int grid = grid_for(nchunks);
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, g_bn_reverse & 1));
   } else if (g_bn_unroll >= 2) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, g_bn_reverse & 1));
   } else {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, g_bn_reverse & 1));
   }
   DPA_CHECK_HIP(hipGetLastError());
 }
@@ -629,7 +637,7 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
   const int grid = grid_for(nchunks);
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
-                                               coef, relu));
+                                               coef, relu, (g_bn_reverse >> 1) & 1));
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -680,5 +688,6 @@ void bn_set_tuning(int grid_blocks, int unroll) {
   g_bn_grid = grid_blocks > 0 ? grid_blocks : 256 * 8;
   g_bn_unroll = unroll > 0 ? unroll : 1;
 }
+void bn_set_reverse(int mask) { g_bn_reverse = mask; }   // bit 0: forward apply, bit 1: backward apply
 
 }  // namespace dpa

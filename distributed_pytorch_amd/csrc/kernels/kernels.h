@@ -86,7 +86,8 @@ void bn_fold_finalize_launch(const float* partial, int nparts, int C, double* tm
 void bn_bwd_fold_finalize_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
                                  const float* gamma, const float* mean, const float* invstd, const float* scale,
                                  const float* shift, float* dgamma, float* dbeta, float* coef, hipStream_t s);
-void bn_set_tuning(int grid_blocks, int unroll);   // tuning hook for the streaming kernels
+void bn_set_tuning(int grid_blocks, int unroll);
+void bn_set_reverse(int mask);   // bit 0 / 1: forward / backward apply kernels walk their tensors from the end   // tuning hook for the streaming kernels
 void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
                      const float* scale, const float* shift, int relu, hipStream_t s);
 // backward: dy masked by (y > 0) when relu; partial [nblk][2][C] = (sum dy, sum dy*xhat)

@@ -24,10 +24,14 @@ from . import grad_sink
 _C = None
 
 
+_BN_REVERSE = int(os.environ.get("DPA_BN_REVERSE", "0"))
+
+
 def C():
     global _C
     if _C is None:
         _C = backend.require()
+        _C.bn_set_reverse(_BN_REVERSE)
     return _C
 
 
