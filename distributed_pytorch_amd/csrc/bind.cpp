@@ -28,8 +28,11 @@ PYBIND11_MODULE(_C, m) {
            int N,
            int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
            int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream,
-           uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu) {
+           uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu, int groups, long a_gstride, long b_gstride,
+           long c_gstride, int stats_ld) {
           IgemmParams p;
+          p.groups = groups; p.a_gstride = a_gstride; p.b_gstride = b_gstride; p.c_gstride = c_gstride;
+          p.stats_ld = stats_ld;
           p.bn_x = ptr<const void>(bn_x);
           p.bn_z = ptr<const void>(bn_z);
           p.bn_coef = ptr<const float>(bn_coef);
@@ -55,7 +58,8 @@ PYBIND11_MODULE(_C, m) {
         py::arg("IH"), py::arg("IW"), py::arg("SY"), py::arg("SX"), py::arg("OH"), py::arg("OW"), py::arg("OHF"),
         py::arg("OWF"), py::arg("OSY"), py::arg("OSX"), py::arg("OY0"), py::arg("OX0"), py::arg("flags"),
         py::arg("dtype"), py::arg("out_dtype"), py::arg("stream"), py::arg("bn_x") = 0, py::arg("bn_z") = 0,
-        py::arg("bn_coef") = 0, py::arg("bn_relu") = 0);
+        py::arg("bn_coef") = 0, py::arg("bn_relu") = 0, py::arg("groups") = 1, py::arg("a_gstride") = 0,
+        py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
   m.def("igemm_tile_m", &igemm_tile_m);
   m.def("igemm_stats_rows", &igemm_stats_rows);
@@ -65,16 +69,17 @@ PYBIND11_MODULE(_C, m) {
   m.def("wgrad_force_config", &wgrad_force_config);
   m.def("wgrad_num_configs", &wgrad_num_configs);
   m.def("wgrad_set_target_blocks", &wgrad_set_target_blocks);
-  m.def("wgrad_choose_splits", [](long M, int N, int Ktot, int dtype) {
+  m.def("wgrad_choose_splits", [](long M, int N, int Ktot, int dtype, int groups) {
     int pps = 0;
-    const int s = wgrad_choose_splits(M, N, Ktot, dtype, &pps);
+    const int s = wgrad_choose_splits(M, N, Ktot, dtype, &pps, groups);
     return py::make_tuple(s, pps);
-  });
+  }, py::arg("M"), py::arg("N"), py::arg("Ktot"), py::arg("dtype"), py::arg("groups") = 1);
   m.def("wgrad",
         [](uintptr_t dY, uintptr_t X, uintptr_t slab, uintptr_t taps, int M, int N, int Cred, int ntaps, int ldy,
            int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int taps_zero, int dtype,
-           uintptr_t stream) {
+           uintptr_t stream, int groups, long y_gstride, long x_gstride) {
           WgradParams p;
+          p.groups = groups; p.y_gstride = y_gstride; p.x_gstride = x_gstride; p.slab_rows = groups * N;
           p.taps_zero = taps_zero;
           p.dY = ptr<const void>(dY);
           p.X = ptr<const void>(X);
@@ -86,7 +91,11 @@ PYBIND11_MODULE(_C, m) {
           p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
           p.div_ow = make_fastdiv((uint32_t)OW);
           wgrad_launch(p, dtype, st(stream));
-        });
+        },
+        py::arg("dY"), py::arg("X"), py::arg("slab"), py::arg("taps"), py::arg("M"), py::arg("N"), py::arg("Cred"),
+        py::arg("ntaps"), py::arg("ldy"), py::arg("ldx"), py::arg("IH"), py::arg("IW"), py::arg("SY"), py::arg("SX"),
+        py::arg("OH"), py::arg("OW"), py::arg("splits"), py::arg("pps"), py::arg("taps_zero"), py::arg("dtype"),
+        py::arg("stream"), py::arg("groups") = 1, py::arg("y_gstride") = 0, py::arg("x_gstride") = 0);
   m.def("slab_reduce", [](uintptr_t slab, int splits, long n, uintptr_t out, int out_dtype, float beta, uintptr_t s) {
     slab_reduce_launch(ptr<const float>(slab), splits, n, ptr<void>(out), out_dtype, beta, st(s));
   });

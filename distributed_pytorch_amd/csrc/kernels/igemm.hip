@@ -62,6 +62,7 @@ template <> struct Mma<float> {
 template <typename TOut, int BM, int BN, bool BNB>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&acc)[BN / 64][BM / 64],
                                                unsigned char* smem, int m0, int n0, int mt) {
+  const long gofs = (long)blockIdx.y * p.c_gstride;      // first output channel of this group
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   constexpr int LDE = BN * (int)sizeof(TOut) + 16;   // epilogue tile row bytes
@@ -88,7 +89,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       float bs[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.bias != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] = (n0 + cch + j < p.N) ? p.bias[n0 + cch + j] : 0.f;
+        for (int j = 0; j < 4; ++j) bs[j] = (n0 + cch + j < p.N) ? p.bias[gofs + n0 + cch + j] : 0.f;
       }
 #pragma unroll
       for (int b = 0; b < MI; ++b) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   float s1[VECO], s2[VECO];
 #pragma unroll
   for (int j = 0; j < VECO; ++j) s1[j] = s2[j] = 0.f;
-  char* __restrict__ Cg = reinterpret_cast<char*>(p.C);
+  char* __restrict__ Cg = reinterpret_cast<char*>(p.C) + gofs * sizeof(TOut);
   // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column, and ALL
   // rows of the extra operands requested at once (inside the store loop each row paid a full memory latency;
   // the accumulators are dead by now, so the 2 x E_IT vectors cost no occupancy)
@@ -160,7 +161,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     const size_t goff = (orow * p.ldc + ncol) * sizeof(TOut);
     char* dst = Cg + goff;
     if (p.R != nullptr) {      // fused accumulate (gradient of a tensor with two consumers): one rounding
-      const char* rsrc = reinterpret_cast<const char*>(p.R) + goff;
+      const char* rsrc = reinterpret_cast<const char*>(p.R) + gofs * sizeof(TOut) + goff;
       if (ncol + VECO <= p.N) {
         Vec16<TOut> r;
         r.load(rsrc);
@@ -238,7 +239,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       if (n0 + col < p.N) {
         const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
                         red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
-        p.stats[((size_t)mt * 2 + which) * p.N + n0 + col] = s;
+        p.stats[((size_t)mt * 2 + which) * p.stats_ld + gofs + n0 + col] = s;
       }
     }
   }
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   const int mt = lid / tiles_n, nt = lid - mt * tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A);
-  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B);
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)blockIdx.y * p.b_gstride * sizeof(T);
 
   // ---- per-thread gather state: rows are fixed for the whole K loop -----------------------
   const int ch = tid % CPR;
@@ -521,8 +522,8 @@ __global__ __launch_bounds__(256, MINB) void igemm_glds_kernel(const IgemmParams
   const int mt = lid / tiles_n, nt = lid - mt * tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A);
-  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B);
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)blockIdx.y * p.b_gstride * sizeof(T);
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
   const int r_in = lane / CPR, cphys = lane % CPR;
@@ -661,7 +662,7 @@ void launch_glds(const IgemmParams& p, hipStream_t stream) {
     attr_done = true;
   }
   const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)p.groups), dim3(256), lds, stream, p);
 }
 
 template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB = false>
@@ -685,7 +686,7 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
     attr_done = true;
   }
   const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)p.groups), dim3(256), lds, stream, p);
 }
 
 // Tile configurations.  0..3 exist for every dtype pair; further experimental ones can be appended for
@@ -775,9 +776,20 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream) {
+void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t stream) {
+  IgemmParams p = p_in;
   const int vec = dtype == kF32 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0) return;
+  if (p.groups <= 1) {
+    p.groups = 1;
+    p.a_gstride = p.b_gstride = p.c_gstride = 0;
+  } else {
+    const int veco_g = out_dtype == kF32 ? 4 : 8;
+    if (p.a_gstride % vec || p.b_gstride % vec || p.c_gstride % veco_g || p.groups > 65535)
+      throw std::invalid_argument("igemm: group slices must start on 16-byte boundaries");
+    if (p.flags & kIgemmBnBwd) throw std::invalid_argument("igemm: fused BN-backward reduction is dense only");
+  }
+  if (p.stats_ld <= 0) p.stats_ld = p.N;
   if (p.Cred % vec != 0 || p.lda % vec != 0 || p.ldb % vec != 0)
     throw std::invalid_argument("igemm: reduction channels / strides must be multiples of 16 bytes");
   const int veco = out_dtype == kF32 ? 4 : 8;

@@ -22,6 +22,12 @@ struct IgemmParams {
   const void* bn_z;    // BN output (bn_relu == 1)
   const float* bn_coef;  // [4][N]: mean, invstd, scale, shift
   int bn_relu;
+  // grouped convolution: grid.y = group; a group's slice starts g * stride ELEMENTS into each operand (groups
+  // <= 1: dense).  N, Cred are per group; bias / statistics are indexed by the global channel g * c_gstride + n,
+  // stats_ld is the slab's row width (all groups; 0 = N).
+  int groups = 1;
+  long a_gstride = 0, b_gstride = 0, c_gstride = 0;
+  int stats_ld = 0;
   const int* taps;     // device int32 triples (dy, dx, wtap), ntaps entries
   int M, N, Cred, ntaps;
   int lda, ldb, ldc;
@@ -49,6 +55,9 @@ struct WgradParams {
   int ldy, ldx;
   int IH, IW, SY, SX;
   int splits, pix_per_split;
+  int groups = 1;      // grid.y = group: dY / X slices start g * stride elements in, slab rows g * N .. (g+1) * N
+  long y_gstride = 0, x_gstride = 0;
+  int slab_rows = 0;   // rows of one split's slab = groups * N
   int taps_zero;       // every tap is (0, 0): a 1x1 convolution without padding (enables the linear fast path)
   FastDiv div_ohow, div_ow;
 };
@@ -56,7 +65,7 @@ void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);
 // out[i] = beta*out[i] + sum_s slab[s][i]   (out dtype f32/bf16/f16), optional column sums
 void slab_reduce_launch(const float* slab, int splits, long n, void* out, int out_dtype, float beta,
                         hipStream_t stream);
-int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split);
+int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split, int groups = 1);
 void wgrad_force_config(int cfg);   // tuning hook, -1 = automatic
 int wgrad_num_configs();
 void wgrad_set_target_blocks(int n);   // tuning hook: workgroups the pixel split aims for

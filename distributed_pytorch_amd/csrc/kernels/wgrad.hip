@@ -65,8 +65,8 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   const int m_begin = split * p.pix_per_split;
   const int m_end = min(p.M, m_begin + p.pix_per_split);
 
-  const char* __restrict__ Yg = reinterpret_cast<const char*>(p.dY);
-  const char* __restrict__ Xg = reinterpret_cast<const char*>(p.X);
+  const char* __restrict__ Yg = reinterpret_cast<const char*>(p.dY) + (size_t)blockIdx.y * p.y_gstride * sizeof(T);
+  const char* __restrict__ Xg = reinterpret_cast<const char*>(p.X) + (size_t)blockIdx.y * p.x_gstride * sizeof(T);
 
   // fixed per-thread columns
   const int cp = tid % CPP;                   // dY chunk column
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   }
 
   // acc[a][b][r]: i = wi*WTI + a*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wj*WTJ + b*32 + l31
-  float* __restrict__ out = p.slab + (size_t)split * p.N * p.Ktot;
+  float* __restrict__ out = p.slab + ((size_t)split * p.slab_rows + (size_t)blockIdx.y * p.N) * p.Ktot;
 #pragma unroll
   for (int a = 0; a < MI; ++a)
 #pragma unroll
@@ -346,11 +346,11 @@ void launch_cfg(const WgradParams& p, hipStream_t stream) {
     attr_done = true;
   }
   if (lin)
-    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF>), dim3((unsigned)blocks), dim3(64 * WI * WJ), lds,
-                       stream, p);
+    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF>), dim3((unsigned)blocks, (unsigned)p.groups),
+                       dim3(64 * WI * WJ), lds, stream, p);
   else
-    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF>), dim3((unsigned)blocks), dim3(64 * WI * WJ), lds,
-                       stream, p);
+    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF>), dim3((unsigned)blocks, (unsigned)p.groups),
+                       dim3(64 * WI * WJ), lds, stream, p);
 }
 
 // Tile configurations (output channels x im2col columns x bytes of pixels per K tile); picked per
@@ -402,16 +402,17 @@ void wgrad_force_config(int cfg) { g_force_wcfg = cfg; }
 void wgrad_set_target_blocks(int n) { g_target_blocks = n > 0 ? n : 768; }
 int wgrad_num_configs() { return kNumWCfgs; }
 
-int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split) {
+int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split, int groups) {
+  if (groups < 1) groups = 1;
   const WCfg c = kWCfgs[choose_wcfg(M, N, Ktot)];
   const int bkp = c.kb / (dtype == kF32 ? 4 : 2);
-  const long tiles = (long)ceil_div(N, c.bi) * ceil_div(Ktot, c.bj);
+  const long tiles = (long)ceil_div(N, c.bi) * ceil_div(Ktot, c.bj) * groups;
   // aim for ~3 workgroups per CU, keep >= 8 K tiles per workgroup, and bound the slab size
   const long target = (long)g_target_blocks * 256 / c.threads;     // same number of waves in flight
   long splits = (target + tiles - 1) / tiles;
   const long max_by_work = (M + 8l * bkp - 1) / (8l * bkp);
   if (splits > max_by_work) splits = max_by_work;
-  const long out_elems = (long)N * Ktot;
+  const long out_elems = (long)N * Ktot * groups;
   const long max_by_slab = (64l << 20) / (out_elems * 4) + 1;   // <= ~64 MiB of partials
   if (splits > max_by_slab) splits = max_by_slab;
   if (splits < 1) splits = 1;
@@ -422,9 +423,18 @@ int wgrad_choose_splits(long M, int N, int Ktot, int dtype, int* pix_per_split) 
   return (int)splits;
 }
 
-void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream) {
+void wgrad_launch(const WgradParams& p_in, int dtype, hipStream_t stream) {
+  WgradParams p = p_in;
   const int vec = dtype == kF32 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0 || p.Ktot <= 0) return;
+  if (p.groups <= 1) {
+    p.groups = 1;
+    p.y_gstride = p.x_gstride = 0;
+    p.slab_rows = p.N;
+  } else {
+    if (p.y_gstride % vec || p.x_gstride % vec || p.groups > 65535 || p.slab_rows != p.groups * p.N)
+      throw std::invalid_argument("wgrad: bad group layout");
+  }
   if (p.N % vec != 0 || p.Cred % vec != 0 || p.ldy % vec != 0 || p.ldx % vec != 0)
     throw std::invalid_argument("wgrad: channel counts / strides must be multiples of 16 bytes");
   if (p.Ktot != p.ntaps * p.Cred) throw std::invalid_argument("wgrad: Ktot != ntaps*Cred");

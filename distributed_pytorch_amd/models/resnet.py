@@ -1,4 +1,4 @@
-"""ResNet family (18/34/50/101/152, wide variants) in NHWC with fused blocks.
+"""ResNet family (18/34/50/101/152, wide and ResNeXt variants) in NHWC with fused blocks.
 
 Architecture and parameter names equal torchvision's ``resnet.py`` v1.5
 (stride on the 3x3 of a bottleneck) so that ``state_dict`` keys —
@@ -26,8 +26,8 @@ from ..ops import functional as F
 STEM_PAD_C = 8  # image channels 3 -> 8 on the GPU so every im2col chunk is one 16-byte vector
 
 
-def conv3x3(cin, cout, stride=1):
-    return Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+def conv3x3(cin, cout, stride=1, groups=1):
+    return Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False, groups=groups)
 
 
 def conv1x1(cin, cout, stride=1):
@@ -37,8 +37,10 @@ def conv1x1(cin, cout, stride=1):
 class BasicBlock(nn.Module):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, base_width=64):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, base_width=64, groups=1):
         super().__init__()
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
         self.conv1 = conv3x3(inplanes, planes, stride)
         self.bn1 = BatchNorm2d(planes)
         self.relu = ReLU(inplace=True)
@@ -58,12 +60,12 @@ class BasicBlock(nn.Module):
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, base_width=64):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, base_width=64, groups=1):
         super().__init__()
-        width = int(planes * (base_width / 64.0))
+        width = int(planes * (base_width / 64.0)) * groups
         self.conv1 = conv1x1(inplanes, width)
         self.bn1 = BatchNorm2d(width)
-        self.conv2 = conv3x3(width, width, stride)
+        self.conv2 = conv3x3(width, width, stride, groups)     # ResNeXt: the cardinality lives here
         self.bn2 = BatchNorm2d(width)
         self.conv3 = conv1x1(width, planes * self.expansion)
         self.bn3 = BatchNorm2d(planes * self.expansion)
@@ -83,9 +85,10 @@ class Bottleneck(nn.Module):
 class ResNet(nn.Module):
     def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int],
                  num_classes: int = 1000, zero_init_residual: bool = False,
-                 width_per_group: int = 64):
+                 groups: int = 1, width_per_group: int = 64):
         super().__init__()
         self.inplanes = 64
+        self.groups = groups
         self.base_width = width_per_group
         self.conv1 = Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.conv1.needs_input_grad = False
@@ -117,10 +120,10 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
                                        BatchNorm2d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample, self.base_width)]
+        layers = [block(self.inplanes, planes, stride, downsample, self.base_width, self.groups)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, base_width=self.base_width))
+            layers.append(block(self.inplanes, planes, base_width=self.base_width, groups=self.groups))
         return nn.Sequential(*layers)
 
     def prepare_input(self, x: torch.Tensor) -> torch.Tensor:
@@ -175,3 +178,15 @@ def wide_resnet50_2(**kw):
 
 def wide_resnet101_2(**kw):
     return _resnet(Bottleneck, [3, 4, 23, 3], width_per_group=128, **kw)
+
+
+def resnext50_32x4d(**kw):
+    return _resnet(Bottleneck, [3, 4, 6, 3], groups=32, width_per_group=4, **kw)
+
+
+def resnext101_32x8d(**kw):
+    return _resnet(Bottleneck, [3, 4, 23, 3], groups=32, width_per_group=8, **kw)
+
+
+def resnext101_64x4d(**kw):
+    return _resnet(Bottleneck, [3, 4, 23, 3], groups=64, width_per_group=4, **kw)

@@ -24,12 +24,14 @@ from .. import amp as _amp
 
 class Conv2d(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0,
-                 bias: bool = True):
+                 bias: bool = True, groups: int = 1):
         super().__init__()
         k = F._pair(kernel_size)
-        self.in_channels, self.out_channels = in_channels, out_channels
+        if in_channels % groups or out_channels % groups:
+            raise ValueError("in_channels and out_channels must be divisible by groups")
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
         self.kernel_size, self.stride, self.padding = k, F._pair(stride), F._pair(padding)
-        w = torch.empty(out_channels, in_channels, k[0], k[1]).contiguous(
+        w = torch.empty(out_channels, in_channels // groups, k[0], k[1]).contiguous(
             memory_format=torch.channels_last)
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
@@ -39,19 +41,19 @@ class Conv2d(nn.Module):
     def reset_parameters(self) -> None:
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            fan_in = self.in_channels // self.groups * self.kernel_size[0] * self.kernel_size[1]
             bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x: torch.Tensor, relu: bool = False, want_stats: bool = False, skip: bool = False):
         return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu=relu,
                         w_lp=_amp.compute_copy(self.weight, x), want_stats=want_stats,
-                        needs_input_grad=self.needs_input_grad, skip=skip)
+                        needs_input_grad=self.needs_input_grad, skip=skip, groups=self.groups)
 
     def extra_repr(self) -> str:
-        return "{}, {}, kernel_size={}, stride={}, padding={}, bias={}".format(
+        return "{}, {}, kernel_size={}, stride={}, padding={}, bias={}{}".format(
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
-            self.bias is not None)
+            self.bias is not None, ", groups=%d" % self.groups if self.groups > 1 else "")
 
 
 class BatchNorm2d(nn.Module):

@@ -41,8 +41,8 @@ def _pair(v) -> Tuple[int, int]:
 # ----------------------------------------------------------------------------- conv
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            stride=1, padding=0, *, relu: bool = False, w_lp: Optional[torch.Tensor] = None,
-           want_stats: bool = False, needs_input_grad: bool = True, skip: bool = False):
-    """NHWC convolution.  ``weight`` is logical ``[K, C, R, S]`` (memory KRSC).
+           want_stats: bool = False, needs_input_grad: bool = True, skip: bool = False, groups: int = 1):
+    """NHWC convolution.  ``weight`` is logical ``[K, C/groups, R, S]`` (memory KRSC).
 
     ``w_lp``: optional low-precision compute copy of ``weight`` (AMP O1/O2);
     gradients still flow to ``weight``.  ``want_stats`` additionally returns the
@@ -50,8 +50,21 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     (feeds the fused BatchNorm).  ``needs_input_grad=False`` skips dgrad (stem).
     ``skip=True`` returns ``(result, x_alias)``: feed ``x_alias`` to the residual branch and its
     gradient is added inside this convolution's dgrad epilogue instead of a separate accumulate pass.
+    ``groups > 1``: grouped / depthwise convolution, every pass one launch with the group on ``grid.y``.
     """
     stride, padding = _pair(stride), _pair(padding)
+    if groups > 1:
+        if _on_gpu(x):
+            out = _hip().group_conv2d(x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad)
+        else:
+            w = weight if w_lp is None else _StraightThroughCast.apply(weight, x.dtype)
+            if w.dtype != x.dtype:
+                w = w.to(x.dtype)
+            b = None if bias is None else bias.to(x.dtype)
+            y = TF.conv2d(x.permute(0, 3, 1, 2), w, b, stride, padding, 1, groups).permute(0, 2, 3, 1)
+            y = (TF.relu(y) if relu else y).contiguous()
+            out = (y, None) if want_stats else y
+        return (out, x) if skip else out
     if _on_gpu(x):
         return _hip().conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats,
                              needs_input_grad, skip)

@@ -225,8 +225,10 @@ def _conv_out(i, k, s, p):
 
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
-           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None):
+           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None):
+    """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group."""
     flags = (C().IGEMM_RELU if relu else 0)
+    gargs = (1, 0, 0, 0, 0) if groups is None else groups
     bn_x = bn_z = bn_coef = bn_relu = 0
     if bnred is not None:               # (bn input, bn output or None, coef[4][N], relu mode)
         flags |= C().IGEMM_BN_BWD
@@ -237,7 +239,7 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
         OHF, OWF, OSY, OSX, OY0, OX0 = scatter
     C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
-              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu)
+              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs)
 
 
 def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
@@ -495,6 +497,164 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
                                     bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None))
     out = (y, stats) if want_stats else y
     return (out, alias) if skip else out
+
+
+# ------------------------------------------------------------------------------------------
+# grouped convolution (ResNeXt cardinality, depthwise): ONE launch per pass, grid.y = group
+# ------------------------------------------------------------------------------------------
+def group_merge(groups: int, Cg: int, Kg: int, vec: int) -> int:
+    """How many consecutive groups one MFMA tile column block covers.
+
+    The matrix cores want >= 64 output channels per tile and 16-byte channel vectors; a group with 4 (ResNeXt
+    32x4d) or 1 (depthwise) channels offers neither.  ``m`` consecutive groups are therefore computed as one
+    block-diagonal group of ``m*Cg -> m*Kg`` channels (zeros off the diagonal: the extra MFMA work is free next
+    to the activation traffic, which is what bounds these layers).  Smallest divisor of ``groups`` that reaches
+    64 channels and keeps every slice 16-byte aligned; all groups merged (a dense block-diagonal conv) at worst."""
+    for m in range(1, groups + 1):
+        if groups % m or (m * Cg) % vec or (m * Kg) % vec:
+            continue
+        if m * min(Cg, Kg) >= 64 or m == groups:
+            return m
+    raise ValueError("grouped conv2d: %d groups of %d -> %d channels cannot be laid out in 16-byte vectors"
+                     % (groups, Cg, Kg))
+
+
+def _gw_src(w: torch.Tensor, Gs: int, m: int) -> torch.Tensor:
+    K, Cg, R, S = w.shape
+    return w.detach().view(Gs, m, K // (Gs * m), Cg, R, S)
+
+
+def group_weight(w: torch.Tensor, dtype: torch.dtype, groups: int, m: int) -> torch.Tensor:
+    """fprop operand [K, R, S, m*Cg]: row k holds its group's filter at channel offset (group % m) * Cg."""
+    if m == 1:
+        return conv_weight(w, dtype, w.shape[1])
+    K, Cg, R, S = w.shape
+    c = _cache(w)
+    key = (dtype, "g", m)
+    if c.wc is not None and c.wc_key == key and c.wc_stamp == _stamp(w):
+        return c.wc
+    Gs, Kg = groups // m, K // groups
+    if c.wc is None or c.wc_key != key:
+        c.wc = torch.zeros((Gs, m, Kg, R, S, m, Cg), dtype=dtype, device=w.device)
+    # only the diagonal blocks are ever written; the zeros around them persist across refreshes
+    torch.diagonal(c.wc, dim1=1, dim2=5).copy_(_gw_src(w, Gs, m).permute(0, 2, 4, 5, 3, 1))
+    c.wc_key, c.wc_stamp = key, _stamp(w)
+    return c.wc
+
+
+def group_weight_t(w: torch.Tensor, dtype: torch.dtype, groups: int, m: int) -> torch.Tensor:
+    """dgrad operand [C, R, S, m*Kg] (input channel major, the merged group's output channels contiguous)."""
+    K, Cg, R, S = w.shape
+    c = _cache(w)
+    key = (dtype, "g", m)
+    if c.wt is not None and c.wt_key == key and c.wt_stamp == _stamp(w):
+        return c.wt
+    Gs, Kg = groups // m, K // groups
+    if c.wt is None or c.wt_key != key:
+        c.wt = torch.zeros((Gs, m, Cg, R, S, m, Kg), dtype=dtype, device=w.device)
+    torch.diagonal(c.wt, dim1=1, dim2=5).copy_(_gw_src(w, Gs, m).permute(0, 3, 4, 5, 2, 1))
+    c.wt_key, c.wt_stamp = key, _stamp(w)
+    return c.wt
+
+
+class _GroupConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, IH, IW, Cx = x.shape
+        K, Cg, R, S = weight.shape
+        if Cx != Cg * groups or K % groups:
+            raise ValueError("conv2d: input channels %d / weight %s / groups %d do not match"
+                             % (Cx, tuple(weight.shape), groups))
+        Kg = K // groups
+        m = group_merge(groups, Cg, Kg, _vec(x.dtype))
+        Gs, Cin, Kout = groups // m, m * Cg, m * Kg
+        sh, sw = stride
+        ph, pw = padding
+        OH, OW = _conv_out(IH, R, sh, ph), _conv_out(IW, S, sw, pw)
+        if OH <= 0 or OW <= 0:
+            raise ValueError("conv2d: input %s too small for kernel %s" % (tuple(x.shape), (R, S)))
+        wc = group_weight(weight, x.dtype, groups, m)
+        y = torch.empty((NB, OH, OW, K), dtype=x.dtype, device=x.device)
+        M = NB * OH * OW
+        stats = None
+        if want_stats:
+            tiles = C().igemm_stats_rows(M, Kout, Cin, R * S, _dt(x), _dt(x))
+            stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+        taps = _tap_table(x.device, _fprop_taps(R, S, ph, pw))
+        bias_f = None
+        if bias is not None:
+            bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
+        _igemm(x, wc, y, bias_f, stats, taps, M, Kout, Cin, R * S, Cx, R * S * Cin, K, IH, IW, sh, sw, OH, OW,
+               relu=relu, dtype=x.dtype, out_dtype=x.dtype, groups=(Gs, Cin, Kout * R * S * Cin, Kout, K))
+        ctx.geom = (stride, padding, groups, m, relu, needs_input_grad, bias is not None)
+        ctx.bias_ref = bias
+        ctx.save_for_backward(x, weight, y if relu else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, dstats=None):
+        x, weight, y = ctx.saved_tensors
+        (sh, sw), (ph, pw), groups, m, relu, needs_input_grad, has_bias = ctx.geom
+        NB, IH, IW, Cx = x.shape
+        K, Cg, R, S = weight.shape
+        Kg = K // groups
+        Gs, Cin, Kout = groups // m, m * Cg, m * Kg
+        OH, OW = dy.shape[1], dy.shape[2]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        M = NB * OH * OW
+        st = _stream()
+        if relu:
+            dym = torch.empty_like(dy)
+            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
+            dy = dym
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and needs_input_grad:
+            wt = group_weight_t(weight, dy.dtype, groups, m)
+            classes = _dgrad_classes(R, S, sh, sw, ph, pw)
+            need_zero = any(len(t) == 0 for _, _, t in classes)
+            dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
+            for py, px, taps in classes:
+                SH, SW = (IH - py + sh - 1) // sh, (IW - px + sw - 1) // sw
+                if not taps or SH <= 0 or SW <= 0:
+                    continue
+                scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
+                _igemm(dy, wt, dx, None, None, _tap_table(dy.device, taps), NB * SH * SW, Cin, Kout, len(taps), K,
+                       R * S * Kout, Cx, OH, OW, 1, 1, SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype,
+                       groups=(Gs, Kout, Cin * R * S * Kout, Cin, 0))
+        if ctx.needs_input_grad[1]:
+            Ktot = R * S * Cin
+            splits, pps = C().wgrad_choose_splits(M, Kout, Ktot, _dt(dy), Gs)
+            slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
+            taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
+            C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, Kout, Cin, R * S, K, Cx, IH, IW,
+                      sh, sw, OH, OW, splits, pps, 1 if (R * S == 1 and ph == 0 and pw == 0) else 0, _dt(dy), st,
+                      Gs, Kout, Cin)
+            sink = grad_sink.sink_of(weight)
+            if m == 1 and sink is not None and _flat_same_layout(sink.view, weight) \
+                    and (weight.is_contiguous(memory_format=torch.channels_last) or R * S == 1):
+                C().slab_reduce(slab.data_ptr(), splits, K * Ktot, sink.view.data_ptr(), _dt(weight.dtype),
+                                sink.beta(), st)
+                sink.delivered()
+            else:
+                full = torch.empty((Gs, m, Kg, R, S, m, Cg), dtype=torch.float32, device=dy.device)
+                C().slab_reduce(slab.data_ptr(), splits, K * Ktot, full.data_ptr(), 0, 0.0, st)
+                # the diagonal blocks are the gradient; the rest multiplied structural zeros
+                g = torch.diagonal(full, dim1=1, dim2=5).permute(0, 5, 1, 4, 2, 3).reshape(K, Cg, R, S)
+                dw = _deliver(weight, g.to(weight.dtype))
+        if has_bias and ctx.needs_input_grad[2]:
+            bias_p = ctx.bias_ref
+            db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def group_conv2d(x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad=True):
+    grad_sink.note_use(weight, bias)
+    y, stats = _GroupConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), int(groups), bool(relu),
+                                  bool(want_stats), bool(needs_input_grad))
+    return (y, stats) if want_stats else y
 
 
 # ------------------------------------------------------------------------------------------

@@ -15,7 +15,8 @@ def _tiny():
 
 def test_param_counts_and_torchvision_key_names():
     want = {"resnet18": 11689512, "resnet50": 25557032, "alexnet": 61100840, "vgg16": 138357544,
-            "squeezenet1_0": 1248424, "squeezenet1_1": 1235496, "densenet121": 7978856, "densenet169": 14149480}
+            "squeezenet1_0": 1248424, "squeezenet1_1": 1235496, "densenet121": 7978856, "densenet169": 14149480,
+            "resnext50_32x4d": 25028904, "wide_resnet50_2": 68883240}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch
@@ -32,6 +33,7 @@ def test_param_counts_and_torchvision_key_names():
               "features.denseblock4.denselayer16.conv2.weight", "features.transition2.conv.weight",
               "features.norm5.bias", "classifier.weight"):
         assert k in dn, k
+    assert models.create_model("resnext50_32x4d").state_dict()["layer1.0.conv2.weight"].shape == (128, 4, 3, 3)
     sq = models.create_model("squeezenet1_1").state_dict()
     assert sq["features.3.squeeze.weight"].shape == (16, 64, 1, 1) and sq["classifier.1.weight"].shape == (1000, 512, 1, 1)
     al = models.create_model("alexnet").state_dict()

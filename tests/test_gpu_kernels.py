@@ -391,3 +391,49 @@ def test_cat_channels_ceil_maxpool_avgpool(dtype):
     x = torch.randn(2, 8, 12, 32, device=DEV).to(dtype)
     _close(F.avg_pool2d(x, 2, 2).permute(0, 3, 1, 2), TF.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2), dtype,
            what="avgpool 2x2")
+
+
+GROUP_CASES = [
+    # N, H, W, Cin, Cout, groups, k, stride, pad
+    (3, 14, 14, 128, 128, 32, 3, 1, 1),     # ResNeXt 32x4d layer1 (16 groups merged per tile)
+    (3, 14, 14, 256, 256, 32, 3, 2, 1),     # ResNeXt stride-2 block
+    (2, 7, 7, 1024, 1024, 32, 3, 1, 1),     # 32 channels per group: 2 merged
+    (2, 9, 11, 128, 256, 2, 3, 1, 1),       # wide groups, no merging (64 -> 128 per group)
+    (2, 14, 14, 96, 96, 96, 3, 1, 1),       # depthwise, every group in one block-diagonal tile
+    (2, 15, 15, 192, 192, 192, 3, 2, 1),    # depthwise stride 2, 64 merged
+    (2, 8, 8, 64, 128, 4, 1, 1, 0),         # grouped 1x1 (wgrad linear fast path)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", GROUP_CASES)
+@pytest.mark.parametrize("bias_relu", [False, True])
+def test_group_conv_fwd_bwd(case, dtype, bias_relu):
+    """Grouped / depthwise convolution (one launch per pass, group on grid.y) against torch's conv2d(groups=)."""
+    N, H, W, Cin, Cout, G, k, s, p = case
+    torch.manual_seed(5)
+    xq = torch.randn(N, H, W, Cin, device=DEV).to(dtype).requires_grad_(True)
+    w = (torch.randn(Cout, Cin // G, k, k, device=DEV) / (Cin // G * k * k) ** 0.5).contiguous(
+        memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(Cout, device=DEV).requires_grad_(True) if bias_relu else None
+    y, stats = F.conv2d(xq, w, b, s, p, relu=bias_relu, groups=G, want_stats=True)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+
+    xr = xq.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True) if b is not None else None
+    yr = TF.conv2d(xr, wr, br, s, p, 1, G)
+    if bias_relu:
+        mask = (y.detach().permute(0, 3, 1, 2) > 0)
+        assert (mask != (yr.detach() > 0)).float().mean().item() < 1e-3
+        yr = yr * mask
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype, what="fprop")
+    yf = y.detach().float().reshape(-1, Cout)
+    _close(stats.sum(0)[0], yf.sum(0), torch.float32, scale=10, what="stats sum")
+    _close(stats.sum(0)[1], (yf * yf).sum(0), torch.float32, scale=10, what="stats sumsq")
+    _close(xq.grad.permute(0, 3, 1, 2), xr.grad, dtype, what="dgrad")
+    _close(w.grad, wr.grad, dtype, what="wgrad")
+    if b is not None:
+        _close(b.grad, br.grad, dtype, what="bias grad")
