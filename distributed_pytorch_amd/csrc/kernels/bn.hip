@@ -43,8 +43,10 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   const bool active = rl < rp;
   const int c0 = (cc0 + col) * VEC;
 
-  // relu: 0 none, 1 mask = (y > 0) read from the saved output, 2 mask = (scale*x + shift > 0) recomputed
-  // from x (no residual): the output tensor is not read at all
+  // relu & 3: 0 none, 1 mask = (y > 0) read from the saved output, 2 mask = (scale*x + shift > 0) recomputed
+  // from x (no residual): the output tensor is not read at all.  relu & 4: ReLU6, the mask also needs y < 6.
+  const int rm = relu & 3;
+  const bool clip = (relu & 4) != 0;
   float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
     for (int j = 0; j < VEC; ++j) {
       mu[j] = mean[c0 + j];
       is[j] = invstd[c0 + j];
-      if (relu == 2) {
+      if (rm == 2) {
         sc[j] = scale[c0 + j];
         sh[j] = shift[c0 + j];
       }
@@ -79,8 +81,10 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       for (int j = 0; j < VEC; ++j) {
         float d = va.get(j);
         const float xv = vx.get(j);
-        if (relu == 1 && !(vy.get(j) > 0.f)) d = 0.f;
-        if (relu == 2 && !(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
+        if (rm != 0) {
+          const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
+          if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
+        }
         const float xh = (xv - mu[j]) * is[j];
         s1[j] += d;
         s2[j] += d * xh;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
         const size_t off = (size_t)(r + u * rp) * C + c0;
         va[u].load(a + off);
         if (MODE == 1) vx[u].load(x + off);
-        if (MODE == 1 && relu == 1) vy[u].load(y + off);
+        if (MODE == 1 && rm == 1) vy[u].load(y + off);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accumulate(va[u], vx[u], vy[u]);
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       Vec16<T> va, vx, vy;
       va.load(a + off);
       if (MODE == 1) vx.load(x + off);
-      if (MODE == 1 && relu == 1) vy.load(y + off);
+      if (MODE == 1 && rm == 1) vy.load(y + off);
       accumulate(va, vx, vy);
     }
   }
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
           float v = vx[u].get(j) * scv[j] + shv[j];
           if (res != nullptr) v += vr[u].get(j);
           if (relu) v = fmaxf(v, 0.f);
+          if (relu & 4) v = fminf(v, 6.f);
           vo.set(j, v);
         }
         vo.store(y + (i + u * stride) * VEC);
@@ -394,6 +399,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       float v = vx.get(j) * scv[j] + shv[j];
       if (res != nullptr) v += vr.get(j);
       if (relu) v = fmaxf(v, 0.f);
+      if (relu & 4) v = fminf(v, 6.f);
       vo.set(j, v);
     }
     vo.store(y + q * VEC);
@@ -466,6 +472,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float ca[VEC], cb[VEC], ck[VEC], sc[VEC], sh[VEC];
+  const int rm = relu & 3;             // see col_reduce_kernel
+  const bool clip = (relu & 4) != 0;
   if (i >= nchunks) return;
   int c0 = (int)((rev ? nchunks - 1 - i : i) % cc) * VEC;
   load_coef<VEC>(coef, c0, ca);
@@ -486,13 +494,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     Vec16<T> vd, vx, vy, vo, vr;
     vd.load(dy + q * VEC);
     vx.load(x + q * VEC);
-    if (relu == 1) vy.load(y + q * VEC);
+    if (rm == 1) vy.load(y + q * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float d = vd.get(j);
       const float xv = vx.get(j);
-      if (relu == 1 && !(vy.get(j) > 0.f)) d = 0.f;
-      if (relu == 2 && !(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
+      if (rm != 0) {
+        const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
+        if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
+      }
       vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
       vr.set(j, d);
     }
@@ -560,7 +570,7 @@ void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, in
 void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, int C, int dtype,
                           const float* mean, const float* invstd, int relu, const float* scale,
                           const float* shift, float* partial, int nblk, hipStream_t s) {
-  if (relu == 2 && (scale == nullptr || shift == nullptr)) throw std::invalid_argument("bn: relu mode 2 needs scale/shift");
+  if ((relu & 3) == 2 && (scale == nullptr || shift == nullptr)) throw std::invalid_argument("bn: relu mode 2 needs scale/shift");
   col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu, scale, shift, partial, nblk, s);
 }
 

@@ -7,11 +7,12 @@ from typing import Callable, Dict, List
 
 from . import alexnet_vgg as _av
 from . import densenet as _dn
+from . import mobilenet as _mb
 from . import resnet as _rn
 from . import squeezenet as _sq
 
 _REGISTRY: Dict[str, Callable] = {}
-for _mod in (_rn, _av, _sq, _dn):
+for _mod in (_rn, _av, _sq, _dn, _mb):
     for _name in dir(_mod):
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("_") and callable(_fn) \

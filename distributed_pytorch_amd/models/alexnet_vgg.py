@@ -17,7 +17,7 @@ from torch import nn
 
 from .. import amp
 from ..nn.modules import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Dropout, Flatten, Linear,
-                          MaxPool2d, ReLU, conv_bn_act)
+                          MaxPool2d, ReLU, ReLU6, conv_bn_act)
 from ..ops import functional as F
 from .resnet import STEM_PAD_C
 
@@ -31,7 +31,7 @@ def run_fused_sequential(seq: nn.Sequential, x, final_dtype=None):
         nxt = mods[i + 1] if i + 1 < n else None
         nxt2 = mods[i + 2] if i + 2 < n else None
         if isinstance(m, Conv2d) and isinstance(nxt, BatchNorm2d):
-            relu = isinstance(nxt2, ReLU)
+            relu = 6 if isinstance(nxt2, ReLU6) else isinstance(nxt2, ReLU)
             x = conv_bn_act(x, m, nxt, relu=relu)
             i += 3 if relu else 2
         elif isinstance(m, Conv2d) and isinstance(nxt, ReLU):

@@ -98,6 +98,17 @@ class ReLU(nn.Module):
         return F.relu(x)
 
 
+class ReLU6(nn.Module):
+    """Placeholder that keeps torchvision's module indices: the zoo applies ReLU6 inside the fused BN pass
+    (``conv_bn_act(..., relu=6)``).  Called on its own it is a plain clamp."""
+
+    def __init__(self, inplace: bool = False):
+        super().__init__()
+
+    def forward(self, x):
+        return torch.clamp(x, 0.0, 6.0)
+
+
 class MaxPool2d(nn.Module):
     def __init__(self, kernel_size, stride=None, padding=0, ceil_mode: bool = False):
         super().__init__()
@@ -176,8 +187,8 @@ class Flatten(nn.Module):
         return x.reshape(x.shape[0], -1)
 
 
-def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool = True, residual=None, skip: bool = False):
-    """conv -> BN(+residual)(+ReLU).  On the GPU the conv epilogue emits the
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False):
+    """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
     re-read for statistics.  ``skip=True`` -> ``(out, x_alias)`` (see ``F.conv2d``)."""
     fuse = F._on_gpu(x) and bn.training and bn.process_group is None

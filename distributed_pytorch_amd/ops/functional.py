@@ -101,6 +101,7 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
     """Fused ``BN [+ residual] [+ ReLU]`` over NHWC (N-K4/K5/K7; SyncBN when
     ``group`` is a process group: N-K6).  Statistics are always fp32.
     ``running_var`` receives the unbiased variance, as in torch / cuDNN.
+    ``relu=6`` applies ReLU6 (MobileNet) inside the same pass.
     """
     if _on_gpu(x):
         return _hip().batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked,
@@ -119,7 +120,7 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
     if residual is not None:
         y = y + residual
     if relu:
-        y = TF.relu(y)
+        y = TF.relu6(y) if (relu is not True and relu == 6) else TF.relu(y)
     return y.contiguous()
 
 

@@ -750,15 +750,16 @@ class _BNFn(torch.autograd.Function):
         if residual is not None and not residual.is_contiguous():
             residual = residual.contiguous()
         y = torch.empty_like(x)
+        clip = 4 if relu == 6 else 0            # ReLU6: bit 2 of the kernels' activation code
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
-                     coef[3].data_ptr(), 1 if relu else 0, st)
+                     coef[3].data_ptr(), (1 if relu else 0) | clip, st)
         # ReLU mask in backward: recomputed from x (scale*x + shift > 0) when there is no residual, so the
         # output is neither saved by this op nor read again; with a residual it comes from y
         relu_mode = 0 if not relu else (1 if residual is not None else 2)
         ctx.save_for_backward(x, y if relu_mode == 1 else None, weight, coef, count_dev)
         ctx.bias_ref = bias
-        ctx.cfg = (relu_mode, residual is not None, group, count)
-        _BNFn.last = _BnSrc(x, coef, relu_mode)
+        ctx.cfg = (relu_mode | clip, residual is not None, group, count)
+        _BNFn.last = None if clip else _BnSrc(x, coef, relu_mode)
         return y
 
     @staticmethod
@@ -843,7 +844,7 @@ class _BNEvalFn(torch.autograd.Function):
             residual = residual.contiguous()
         y = torch.empty_like(x)
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[0].data_ptr(),
-                     coef[1].data_ptr(), 1 if relu else 0, st)
+                     coef[1].data_ptr(), (1 if relu else 0) | (4 if relu == 6 else 0), st)
         ctx.save_for_backward(y if relu else None, coef)
         ctx.cfg = (relu, residual is not None)
         return y
@@ -859,10 +860,15 @@ class _BNEvalFn(torch.autograd.Function):
         if relu:
             dym = torch.empty_like(dy)
             C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
-            dy = dym
+            dy = dym * (y < 6) if relu == 6 else dym     # eval-mode backward (fine-tuning frozen BN) is not a hot path
         dx = torch.empty_like(dy)
         C().bn_apply(dy.data_ptr(), 0, dx.data_ptr(), M, Cc, _dt(dy), coef[0].data_ptr(), coef[2].data_ptr(), 0, st)
         return dx, None, None, (dy if has_res else None), None, None, None, None
+
+
+def _act_code(relu) -> int:
+    """False / True / 6 -> 0 (none), 1 (ReLU), 6 (ReLU6)."""
+    return 6 if (relu is not True and relu == 6) else (1 if relu else 0)
 
 
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps,
@@ -872,12 +878,12 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
         _BNFn.last = None
         y = _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
                         running_var if training else None, num_batches_tracked if training else None,
-                        float(momentum if momentum is not None else 0.1), float(eps), bool(relu), stats, group)
+                        float(momentum if momentum is not None else 0.1), float(eps), _act_code(relu), stats, group)
         if _BNFn.last is not None and torch.is_grad_enabled():
             y._dpa_bn = _BNFn.last      # lets the consuming convolution fuse this BN's backward reduction
             _BNFn.last = None
         return y
-    return _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), bool(relu))
+    return _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), _act_code(relu))
 
 
 # ------------------------------------------------------------------------------------------

@@ -16,7 +16,8 @@ def _tiny():
 def test_param_counts_and_torchvision_key_names():
     want = {"resnet18": 11689512, "resnet50": 25557032, "alexnet": 61100840, "vgg16": 138357544,
             "squeezenet1_0": 1248424, "squeezenet1_1": 1235496, "densenet121": 7978856, "densenet169": 14149480,
-            "resnext50_32x4d": 25028904, "wide_resnet50_2": 68883240}
+            "resnext50_32x4d": 25028904, "wide_resnet50_2": 68883240,
+            "mobilenet_v2": 3504872, "mnasnet1_0": 4383312, "mnasnet0_5": 2218512}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch
@@ -34,6 +35,9 @@ def test_param_counts_and_torchvision_key_names():
               "features.norm5.bias", "classifier.weight"):
         assert k in dn, k
     assert models.create_model("resnext50_32x4d").state_dict()["layer1.0.conv2.weight"].shape == (128, 4, 3, 3)
+    mb = models.create_model("mobilenet_v2").state_dict()
+    assert mb["features.2.conv.1.0.weight"].shape == (96, 1, 3, 3) and mb["features.18.1.running_var"].shape == (1280,)
+    assert models.create_model("mnasnet1_0").state_dict()["layers.9.0.layers.3.weight"].shape == (72, 1, 5, 5)
     sq = models.create_model("squeezenet1_1").state_dict()
     assert sq["features.3.squeeze.weight"].shape == (16, 64, 1, 1) and sq["classifier.1.weight"].shape == (1000, 512, 1, 1)
     al = models.create_model("alexnet").state_dict()

@@ -437,3 +437,42 @@ def test_group_conv_fwd_bwd(case, dtype, bias_relu):
     _close(w.grad, wr.grad, dtype, what="wgrad")
     if b is not None:
         _close(b.grad, br.grad, dtype, what="bias grad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_relu6(dtype, res, training):
+    """BN (+residual) + ReLU6 in one pass (activation code 6); backward masks 0 < y < 6.  The reference takes the
+    kernel's own mask: an output within bf16 rounding of 6 may land on either side."""
+    torch.manual_seed(4)
+    N, H, W, C = 4, 7, 9, 96
+    x = (torch.randn(N, H, W, C, device=DEV) * 2 + 0.5).to(dtype).requires_grad_(True)
+    r = torch.randn(N, H, W, C, device=DEV).to(dtype).requires_grad_(True) if res else None
+    g = (torch.rand(C, device=DEV) * 3 + 2).requires_grad_(True)
+    b = (torch.randn(C, device=DEV) + 2).requires_grad_(True)
+    rm, rv = torch.randn(C, device=DEV) * 0.1 + 0.5, torch.rand(C, device=DEV) + 3.5
+    rm2, rv2 = rm.clone(), rv.clone()
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    y = F.batch_norm(x, g, b, rm, rv, nbt if training else None, training, 0.1, 1e-5, relu=6, residual=r)
+    assert 0.02 < (y.detach() >= 6).float().mean().item() < 0.6 and (y.detach() <= 0).float().mean().item() > 0.02
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    rr = r.detach().float().permute(0, 3, 1, 2).requires_grad_(True) if res else None
+    gr, br = g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    pre = TF.batch_norm(xr, rm2, rv2, gr, br, training, 0.1, 1e-5)
+    if res:
+        pre = pre + rr
+    _close(y.permute(0, 3, 1, 2), TF.relu6(pre), dtype, what="y")
+    yk = y.detach().permute(0, 3, 1, 2)
+    mask = (yk > 0) & (yk < 6)
+    assert (mask != ((pre > 0) & (pre < 6))).float().mean().item() < 2e-2
+    (pre * mask).backward(gy.float().permute(0, 3, 1, 2))
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype, scale=4, what="dx")
+    if training:
+        _close(g.grad, gr.grad, dtype, scale=8, what="dgamma")
+        _close(b.grad, br.grad, dtype, scale=8, what="dbeta")
+    if res:
+        _close(r.grad.permute(0, 3, 1, 2), rr.grad, dtype, what="dres")
