@@ -19,6 +19,19 @@ from .. import backend
 
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2, torch.int64: 3, torch.uint8: 4}
 _COUNTER = [0]
+# Small fp32 all-reduces (SyncBN statistics: 2C+1 floats, packed metrics) skip RCCL: one kernel on the caller's
+# stream reads every peer's slot over xGMI (csrc/comm/p2p.hip).  DPA_P2P=0 keeps everything on RCCL.
+P2P_CAPACITY_FLOATS = 16384
+_shared = [None]            # the process's NativeComm, for callers that only hold a tensor (process_group facade)
+
+
+def shared() -> Optional["NativeComm"]:
+    return _shared[0]
+
+
+class _OnCurrentStream:
+    def wait(self):
+        return True
 
 
 class _StreamWait:
@@ -34,11 +47,15 @@ class NativeComm:
     backend = "rccl-native"
     supports_avg = True
 
-    def __init__(self, raw, group=None):
+    def __init__(self, raw, group=None, exchange=None):
         self.raw = raw
         self.group = group
         self.world_size = raw.world_size
         self.rank = raw.rank
+        self._exchange = exchange       # collective: bytes of this rank -> list of every rank's bytes
+        self._p2p = None                # PeerAllReduce, False (unavailable) or None (not set up yet)
+        self.p2p_calls = 0
+        _shared[0] = self
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -58,13 +75,78 @@ class NativeComm:
         dist.broadcast_object_list(holder, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                    group=group)
         raw = ext.Communicator(holder[0], rank, world, device)
-        comm = cls(raw, group)
+
+        def exchange(payload: bytes):
+            out = [None] * world
+            dist.all_gather_object(out, payload, group=group)
+            return out
+
+        comm = cls(raw, group, exchange)
         comm._self_test()
         return comm
 
+    # ------------------------------------------------------------------ small-message peer path
+    def _agree(self, ok: bool) -> bool:
+        """True only if every rank says ok (through RCCL, so all ranks take the same branch)."""
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device="cuda")
+        self._order_after_current()
+        self.raw.all_reduce(flag.data_ptr(), 1, 0, False, 0)
+        _StreamWait(self.raw).wait()
+        return float(flag.item()) == float(self.world_size)
+
+    def _setup_p2p(self):
+        """Collective.  Allocates this rank's fine-grained slot buffer, swaps hipIpc handles, maps the peers and
+        checks three known sums (both slot parities) before the path is used."""
+        if os.environ.get("DPA_P2P", "1") == "0" or self._exchange is None or not 2 <= self.world_size <= 16:
+            return False
+        ext = backend.require()
+        peer, handle = None, b"-"
+        try:
+            peer = ext.PeerAllReduce(self.rank, self.world_size, torch.cuda.current_device(), P2P_CAPACITY_FLOATS,
+                                     float(os.environ.get("DPA_P2P_TIMEOUT_S", "30")))
+            handle = bytes(peer.handle())
+        except Exception:  # noqa: BLE001
+            peer = None
+        handles = self._exchange(handle)
+        ok = peer is not None and all(len(h) == 64 for h in handles)
+        if ok:
+            try:
+                peer.open_peers([bytes(h) for h in handles])
+            except Exception:  # noqa: BLE001
+                ok = False
+        if not self._agree(ok):
+            return False
+        base = torch.arange(1, 1025, dtype=torch.float32, device="cuda")
+        want = base * (self.world_size * (self.world_size + 1) / 2.0)
+        good = True
+        for n in (1024, 3, 1024):
+            t = (base * float(self.rank + 1))[:n].contiguous()
+            peer.all_reduce(t.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.current_stream().synchronize()
+            good = good and peer.status() == 0 and bool(torch.equal(t, want[:n]))
+        if not self._agree(good):
+            return False
+        return peer
+
+    def peer_path(self):
+        if self._p2p is None:
+            self._p2p = self._setup_p2p()
+        return self._p2p or None
+
+    def _small(self, t: torch.Tensor) -> bool:
+        if t.dtype != torch.float32 or not t.is_cuda or t.numel() > P2P_CAPACITY_FLOATS or not t.is_contiguous() \
+                or self._p2p is False:
+            return False
+        peer = self.peer_path()
+        if peer is None:
+            return False
+        peer.all_reduce(t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+        self.p2p_calls += 1
+        return True
+
     def _self_test(self) -> None:
         t = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device="cuda")
-        self.all_reduce_sum(t).wait()
+        self._rccl_sum(t).wait()
         torch.cuda.current_stream().synchronize()
         want = self.world_size * (self.world_size + 1) / 2.0
         got = float(t[0].item())
@@ -83,10 +165,15 @@ class NativeComm:
             h.wait()
         return h
 
-    def all_reduce_sum(self, t: torch.Tensor, async_op: bool = True):
+    def _rccl_sum(self, t: torch.Tensor):
         self._order_after_current()
         self.raw.all_reduce(t.data_ptr(), t.numel(), _DT[t.dtype], False, 0)
-        h = _StreamWait(self.raw)
+        return _StreamWait(self.raw)
+
+    def all_reduce_sum(self, t: torch.Tensor, async_op: bool = True):
+        if self._small(t):
+            return _OnCurrentStream()          # already ordered on the caller's stream
+        h = self._rccl_sum(t)
         if not async_op:
             h.wait()
         return h
@@ -108,7 +195,7 @@ class NativeComm:
 
     def barrier(self):
         t = torch.zeros(1, dtype=torch.float32, device="cuda")
-        self.all_reduce_sum(t).wait()
+        self._rccl_sum(t).wait()
         torch.cuda.current_stream().synchronize()
 
     def make_reducer(self, flats, param_bucket):

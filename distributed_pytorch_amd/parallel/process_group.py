@@ -134,7 +134,7 @@ class NativeProcessGroup:
                 self.store.set("rccl_unique_id", bytes(ext.rccl_unique_id()))
             uid = self.store.get("rccl_unique_id")
             raw = ext.Communicator(uid, self.rank, self.world_size, torch.cuda.current_device())
-            self.gpu_comm = NativeComm(raw, None)
+            self.gpu_comm = NativeComm(raw, None, self.host_comm._exchange)
             self.gpu_comm._self_test()
 
     def comm_for(self, t: Optional[torch.Tensor] = None):
@@ -224,7 +224,15 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     if _NATIVE is not None:
         _NATIVE.comm_for(t).all_reduce_sum(t, async_op=False)
     elif is_initialized():
-        _tdist().all_reduce(t, op=_tdist().ReduceOp.SUM, group=group)
+        nc = None
+        if t.is_cuda and group is None:
+            from .native_comm import shared
+
+            nc = shared()           # DDP's native communicator: small messages take the peer-memory path
+        if nc is not None:
+            nc.all_reduce_sum(t, async_op=False)
+        else:
+            _tdist().all_reduce(t, op=_tdist().ReduceOp.SUM, group=group)
     return t
 
 

@@ -121,3 +121,52 @@ def store_ops(local_rank, world, port, out_dir):
                 "rank": pg.get_rank(), "world": pg.get_world_size(), "backend": pg.get_backend()},
                os.path.join(out_dir, "rank%d.pt" % local_rank))
     _finish()
+
+
+def p2p_allreduce(local_rank, world, port, out_dir):
+    """One-shot peer-memory all-reduce between processes that share ONE GPU (hipIpc mappings of each other's
+    fine-grained slot buffers): sizes from 1 float to the slot capacity, then 300 calls queued back to back without
+    a host sync in between (slot parity reuse)."""
+    from distributed_pytorch_amd import backend
+
+    ext = backend.require()
+    torch.cuda.set_device(0)
+    store = ext.TcpStore("127.0.0.1", int(port), local_rank == 0, 60.0)
+    peer = ext.PeerAllReduce(local_rank, world, 0, 16384, 20.0)
+    store.set("h/%d" % local_rank, bytes(peer.handle()))
+    peer.open_peers([bytes(store.get("h/%d" % r)) for r in range(world)])
+    store.barrier("opened", world)
+    stream = torch.cuda.current_stream().cuda_stream
+    scale = world * (world + 1) / 2.0
+    results = []
+    for it, n in enumerate([1, 7, 1024, 4097, 16384, 5] + [129] * 300):
+        base = torch.arange(n, device="cuda", dtype=torch.float32) % 97 + float(it % 50)
+        t = base * float(local_rank + 1)
+        peer.all_reduce(t.data_ptr(), n, stream)
+        results.append((t, base * scale))
+        if it < 6:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    bad = [i for i, (t, want) in enumerate(results) if not torch.equal(t, want)]
+
+    # the same path as NativeComm wires it up (handle exchange, agreement, self-test, routing by size / dtype);
+    # only the agreement vote is replaced, because RCCL itself cannot run several ranks on one device
+    import types
+
+    from distributed_pytorch_amd.parallel import native_comm
+    from distributed_pytorch_amd.parallel.process_group import StoreComm
+
+    class _VoteThroughStore(native_comm.NativeComm):
+        def _agree(self, ok):
+            return all(p == b"1" for p in self._exchange(b"1" if ok else b"0"))
+
+    comm = _VoteThroughStore(types.SimpleNamespace(world_size=world, rank=local_rank), None,
+                             StoreComm(store, local_rank, world)._exchange)
+    v = torch.full((2 * 2048 + 1,), float(local_rank + 1), device="cuda")        # SyncBN message of a 2048-ch layer
+    comm.all_reduce_sum(v, async_op=False)
+    torch.cuda.synchronize()
+    routed = comm.p2p_calls == 1 and bool(torch.equal(v, torch.full_like(v, scale))) and native_comm.shared() is comm
+    torch.save({"bad": bad, "status": int(peer.status()), "calls": len(results), "routed": routed},
+               os.path.join(out_dir, "rank%d.pt" % local_rank))
+    store.barrier("done", world)
+    del peer, comm

@@ -129,3 +129,25 @@ def test_native_process_group_bootstraps_rccl_through_tcpstore():
     finally:
         os.environ.pop("DPA_FORCE_NATIVE_REDUCER", None)
         pg.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_memory_allreduce_between_processes_sharing_the_gpu(world, tmp_path):
+    """csrc/comm/p2p.hip: the small-message all-reduce (SyncBN statistics, packed metrics) that reads peers' slots
+    directly instead of going through RCCL.  RCCL refuses two ranks on one device, hipIpc does not: W processes map
+    each other's buffers on this one GPU and must agree on every sum."""
+    import socket
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _dist_workers as W
+    from distributed_pytorch_amd import launch
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    launch.spawn(W.p2p_allreduce, world, (world, port, str(tmp_path)))
+    for r in range(world):
+        out = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True)
+        assert out["status"] == 0 and out["bad"] == [] and out["calls"] == 306 and out["routed"], out
