@@ -692,16 +692,18 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
 // Tile configurations.  0..3 exist for every dtype pair; further experimental ones can be appended for
 // 16-bit in == out (the training hot path) and timed per layer with `bench/conv_layers.py --sweep`
 // (igemm_force_config); profiles/r1_igemm_sweep.md holds the sweep the heuristic below came from.
-struct TileCfg { int bm, bn, bkb, minb; };
+struct TileCfg { int bm, bn, bkb, minb; bool glds; };
 constexpr TileCfg kCfgs[] = {
-    {128, 128, 128, 2}, {128, 64, 128, 2}, {128, 128, 64, 2}, {128, 64, 64, 2},   // 0..3 (all dtypes)
+    {128, 128, 128, 2, false}, {128, 64, 128, 2, false}, {128, 128, 64, 2, false}, {128, 64, 64, 2, false},   // 0..3 (all dtypes)
     // LDS-DMA ring kernels (16-bit in == out): 4: 64B x3  5: 64B x4  6: 128B x3  7: narrow 64B x4
-    // 8: 128B x2  9: narrow 128B x3
-    {128, 128, 64, 3}, {128, 128, 64, 2}, {128, 128, 128, 1}, {128, 64, 64, 3},
-    {128, 128, 128, 2}, {128, 64, 128, 2},
+    // 8: 128B x2  9: narrow 128B x3 (tap table in lanes: <= 64 taps)
+    {128, 128, 64, 3, true}, {128, 128, 64, 2, true}, {128, 128, 128, 1, true}, {128, 64, 64, 3, true},
+    {128, 128, 128, 2, true}, {128, 64, 128, 2, true},
+    // 10..13: register-staged 256x128 / 128x256 tiles (a wave owns 128x64 / 64x128): half the operand bytes per
+    // MFMA through L2 and LDS; for the deep 3x3 layers, whose 128x128 tiles re-read the whole filter per tile
+    {256, 128, 64, 2, false}, {128, 256, 64, 2, false}, {256, 128, 128, 1, false}, {128, 256, 128, 1, false},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kNumRegCfgs = 4;     // 0..3 register-staged; the rest are LDS-DMA ring kernels (tap table in lanes)
 
 int g_force_cfg = -1;
 
@@ -714,7 +716,7 @@ int choose_cfg(int M, int N, int Cred, int ntaps, int esize, bool ext) {
   const bool k128 = Cred % (128 / esize) == 0;
   if (g_force_cfg >= 0 && ext && g_force_cfg < kNumCfgs) {
     const TileCfg c = kCfgs[g_force_cfg];
-    if (Cred % (c.bkb / esize) == 0 && (g_force_cfg < kNumRegCfgs || ntaps <= 64)) return g_force_cfg;
+    if (Cred % (c.bkb / esize) == 0 && (!c.glds || ntaps <= 64)) return g_force_cfg;
   }
   const bool wide = N > 64;
   const long tiles = (long)ceil_div(M, 128) * ceil_div(N, wide ? 128 : 64);
@@ -768,6 +770,10 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
       case 7: launch_glds<T, TOut, 128, 64, 64, 4, 3>(p, stream); return;
       case 8: launch_glds<T, TOut, 128, 128, 128, 2, 2>(p, stream); return;
       case 9: launch_glds<T, TOut, 128, 64, 128, 3, 2>(p, stream); return;
+      case 10: launch_cfg<T, TOut, 256, 128, 64, 2, true>(p, stream); return;
+      case 11: launch_cfg<T, TOut, 128, 256, 64, 2, true>(p, stream); return;
+      case 12: launch_cfg<T, TOut, 256, 128, 128, 1, true>(p, stream); return;
+      case 13: launch_cfg<T, TOut, 128, 256, 128, 1, true>(p, stream); return;
       default: break;
     }
   }
