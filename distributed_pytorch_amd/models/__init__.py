@@ -7,17 +7,19 @@ from typing import Callable, Dict, List
 
 from . import alexnet_vgg as _av
 from . import densenet as _dn
+from . import googlenet as _gn
 from . import mobilenet as _mb
+from . import regnet as _rg
 from . import resnet as _rn
 from . import squeezenet as _sq
 
 _REGISTRY: Dict[str, Callable] = {}
-for _mod in (_rn, _av, _sq, _dn, _mb):
+for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg):
     for _name in dir(_mod):
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("_") and callable(_fn) \
                 and getattr(_fn, "__module__", "") == _mod.__name__ \
-                and _name not in ("conv3x3", "conv1x1", "run_fused_sequential"):
+                and _name not in ("conv3x3", "conv1x1", "run_fused_sequential", "block_params"):
             _REGISTRY[_name] = _fn
 
 

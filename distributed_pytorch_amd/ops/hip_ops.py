@@ -507,16 +507,17 @@ def group_merge(groups: int, Cg: int, Kg: int, vec: int) -> int:
 
     The matrix cores want >= 64 output channels per tile and 16-byte channel vectors; a group with 4 (ResNeXt
     32x4d) or 1 (depthwise) channels offers neither.  ``m`` consecutive groups are therefore computed as one
-    block-diagonal group of ``m*Cg -> m*Kg`` channels (zeros off the diagonal: the extra MFMA work is free next
-    to the activation traffic, which is what bounds these layers).  Smallest divisor of ``groups`` that reaches
-    64 channels and keeps every slice 16-byte aligned; all groups merged (a dense block-diagonal conv) at worst."""
-    for m in range(1, groups + 1):
-        if groups % m or (m * Cg) % vec or (m * Kg) % vec:
-            continue
-        if m * min(Cg, Kg) >= 64 or m == groups:
-            return m
-    raise ValueError("grouped conv2d: %d groups of %d -> %d channels cannot be laid out in 16-byte vectors"
-                     % (groups, Cg, Kg))
+    block-diagonal group of ``m*Cg -> m*Kg`` channels (zeros off the diagonal).  A tile computes 64 output
+    channels whether they are used or not, so MFMA work is ``~ roundup(m*Kg, 64) * Cg`` per input channel group:
+    merging is free up to 64 output channels and only then starts to cost.  Hence: the LARGEST divisor of
+    ``groups`` with ``m*Kg <= 64`` whose slices are 16-byte aligned (fewest, fullest tiles); if there is none
+    (wide groups, or alignment needs more), the smallest aligned divisor."""
+    ok = [m for m in range(1, groups + 1) if groups % m == 0 and (m * Cg) % vec == 0 and (m * Kg) % vec == 0]
+    if not ok:
+        raise ValueError("grouped conv2d: %d groups of %d -> %d channels cannot be laid out in 16-byte vectors"
+                         % (groups, Cg, Kg))
+    fit = [m for m in ok if m * Kg <= 64]
+    return max(fit) if fit else min(ok)
 
 
 def _gw_src(w: torch.Tensor, Gs: int, m: int) -> torch.Tensor:

@@ -17,7 +17,8 @@ def test_param_counts_and_torchvision_key_names():
     want = {"resnet18": 11689512, "resnet50": 25557032, "alexnet": 61100840, "vgg16": 138357544,
             "squeezenet1_0": 1248424, "squeezenet1_1": 1235496, "densenet121": 7978856, "densenet169": 14149480,
             "resnext50_32x4d": 25028904, "wide_resnet50_2": 68883240,
-            "mobilenet_v2": 3504872, "mnasnet1_0": 4383312, "mnasnet0_5": 2218512}
+            "mobilenet_v2": 3504872, "mnasnet1_0": 4383312, "mnasnet0_5": 2218512,
+            "googlenet": 6624904, "regnet_x_400mf": 5495976, "regnet_x_1_6gf": 9190136, "regnet_x_8gf": 39572648}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch
@@ -38,6 +39,11 @@ def test_param_counts_and_torchvision_key_names():
     mb = models.create_model("mobilenet_v2").state_dict()
     assert mb["features.2.conv.1.0.weight"].shape == (96, 1, 3, 3) and mb["features.18.1.running_var"].shape == (1280,)
     assert models.create_model("mnasnet1_0").state_dict()["layers.9.0.layers.3.weight"].shape == (72, 1, 5, 5)
+    gn = models.create_model("googlenet", aux_logits=True).state_dict()
+    assert gn["inception4a.branch3.1.conv.weight"].shape == (48, 16, 3, 3) and gn["aux1.fc1.weight"].shape == (1024, 2048)
+    rg = models.create_model("regnet_x_400mf").state_dict()
+    assert rg["trunk_output.block3.block3-0.f.b.0.weight"].shape == (160, 16, 3, 3) and "stem.1.running_mean" in rg \
+        and "trunk_output.block2.block2-0.proj.0.weight" in rg
     sq = models.create_model("squeezenet1_1").state_dict()
     assert sq["features.3.squeeze.weight"].shape == (16, 64, 1, 1) and sq["classifier.1.weight"].shape == (1000, 512, 1, 1)
     al = models.create_model("alexnet").state_dict()

@@ -402,6 +402,8 @@ GROUP_CASES = [
     (2, 14, 14, 96, 96, 96, 3, 1, 1),       # depthwise, every group in one block-diagonal tile
     (2, 15, 15, 192, 192, 192, 3, 2, 1),    # depthwise stride 2, 64 merged
     (2, 8, 8, 64, 128, 4, 1, 1, 0),         # grouped 1x1 (wgrad linear fast path)
+    (2, 14, 14, 72, 72, 3, 3, 1, 1),        # RegNetX-1.6GF: 24 channels per group, K tiles straddle taps
+    (2, 14, 14, 400, 400, 25, 3, 2, 1),     # RegNetX-400MF last stage: 25 groups of 16, unmerged
 ]
 
 

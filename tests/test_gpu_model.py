@@ -22,7 +22,8 @@ def _run(model, x, t):
 
 @pytest.mark.parametrize("arch,size,tol", [("resnet18", 64, 2e-3), ("resnet50", 128, 3e-3), ("alexnet", 224, 2e-3),
                                            ("vgg11_bn", 128, 3e-3), ("squeezenet1_1", 127, 2e-3), ("squeezenet1_0", 96, 2e-3),
-                                           ("densenet121", 64, 3e-3), ("resnext50_32x4d", 128, 4e-3), ("mobilenet_v2", 96, 4e-3), ("mnasnet0_5", 96, 4e-3)])
+                                           ("densenet121", 64, 3e-3), ("resnext50_32x4d", 128, 4e-3), ("mobilenet_v2", 96, 4e-3), ("mnasnet0_5", 96, 4e-3),
+                                           ("googlenet", 96, 3e-3), ("regnet_x_400mf", 96, 4e-3)])
 def test_fp32_model_matches_cpu_reference(arch, size, tol):
     from distributed_pytorch_amd import amp, models
 
