@@ -182,6 +182,27 @@ PYBIND11_MODULE(_C, m) {
                           int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
     maxpool_fwd_launch(ptr<const void>(x), ptr<void>(y), ptr<uint8_t>(idx), NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype, st(s));
   });
+  m.def("bn_relu_maxpool_partial_rows", &bn_relu_maxpool_partial_rows);
+  m.def("bn_relu_maxpool_fwd", [](uintptr_t x, uintptr_t y, uintptr_t idx, uintptr_t scale, uintptr_t shift, int NB, int IH,
+                                  int IW, int C, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
+                                  uintptr_t s) {
+    bn_relu_maxpool_fwd_launch(ptr<const void>(x), ptr<void>(y), ptr<uint8_t>(idx), ptr<const float>(scale),
+                               ptr<const float>(shift), NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype, st(s));
+  });
+  m.def("bn_relu_maxpool_bwd_reduce", [](uintptr_t idx, uintptr_t dyp, uintptr_t x, uintptr_t bn, uintptr_t partial,
+                                         int nblk, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw, int sh,
+                                         int sw, int ph, int pw, int dtype, uintptr_t s) {
+    bn_relu_maxpool_bwd_reduce_launch(ptr<const uint8_t>(idx), ptr<const void>(dyp), ptr<const void>(x),
+                                      ptr<const float>(bn), ptr<float>(partial), nblk, NB, IH, IW, C, OH, OW, kh, kw, sh,
+                                      sw, ph, pw, dtype, st(s));
+  });
+  m.def("bn_relu_maxpool_bwd_apply", [](uintptr_t idx, uintptr_t dyp, uintptr_t x, uintptr_t bn, uintptr_t coef,
+                                        uintptr_t dx, int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw, int sh,
+                                        int sw, int ph, int pw, int dtype, uintptr_t s) {
+    bn_relu_maxpool_bwd_apply_launch(ptr<const uint8_t>(idx), ptr<const void>(dyp), ptr<const void>(x),
+                                     ptr<const float>(bn), ptr<const float>(coef), ptr<void>(dx), NB, IH, IW, C, OH, OW,
+                                     kh, kw, sh, sw, ph, pw, dtype, st(s));
+  });
   m.def("maxpool_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, int NB, int IH, int IW, int C, int OH, int OW,
                           int kh, int kw, int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
     maxpool_bwd_launch(ptr<const uint8_t>(x), ptr<const void>(dy), ptr<void>(dx), NB, IH, IW, C, OH, OW, kh, kw, sh, sw,

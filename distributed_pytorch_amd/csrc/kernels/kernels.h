@@ -125,6 +125,18 @@ void maxpool_fwd_launch(const void* x, void* y, uint8_t* idx, int NB, int IH, in
 void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, int IH, int IW, int C,
                         int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw, int dtype,
                         hipStream_t s);
+// stem fusion: y = maxpool(relu(scale*x + shift)) without materialising the normalised tensor; backward gathers the
+// pooled gradient through the arg-max codes inside the BatchNorm reduce / apply passes (bn = [mean|invstd|scale|shift])
+int bn_relu_maxpool_partial_rows(long in_chunks);
+void bn_relu_maxpool_fwd_launch(const void* x, void* y, uint8_t* idx, const float* scale, const float* shift, int NB,
+                                int IH, int IW, int C, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw,
+                                int dtype, hipStream_t s);
+void bn_relu_maxpool_bwd_reduce_launch(const uint8_t* idx, const void* dyp, const void* x, const float* bn,
+                                       float* partial, int nblk, int NB, int IH, int IW, int C, int OH, int OW, int kh,
+                                       int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
+void bn_relu_maxpool_bwd_apply_launch(const uint8_t* idx, const void* dyp, const void* x, const float* bn,
+                                      const float* coef, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
+                                      int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,
                         int dtype, hipStream_t s);
 void avgpool_bwd_launch(const void* dy, void* dx, int NB, int IH, int IW, int C, int OH, int OW,

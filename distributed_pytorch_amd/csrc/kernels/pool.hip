@@ -13,22 +13,40 @@ struct PoolGeom {
   int NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                          uint8_t* __restrict__ idx, PoolGeom g, long total) {
-  constexpr int VEC = 16 / (int)sizeof(T);
-  const int cc = g.C / VEC;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int c = (int)(i % cc);
-    long pix = i / cc;
-    const int ox = (int)(pix % g.OW); pix /= g.OW;
-    const int oy = (int)(pix % g.OH);
-    const int n = (int)(pix / g.OH);
-    float m[VEC];
-    int am[VEC];   // first arg-max in scan order (torch semantics), as the tap code r*kw + q
+// Window scan of output (n, oy, ox), channels c*VEC..: max and FIRST arg-max in scan order (torch semantics) as
+// the tap code r*kw + q.  KH, KW > 0: compile-time window, every tap loaded up front from a clamped address
+// (all loads in flight at once; a runtime-bounded loop serialises one memory latency per tap).  BN: the values
+// are relu(scale*x + shift) rounded to T, i.e. what a stand-alone BatchNorm pass would have stored.
+template <typename T, int VEC, int KH, int KW, bool BN>
+__device__ __forceinline__ void window_max(const T* __restrict__ x, const PoolGeom& g, uint32_t n, int oy, int ox, int c,
+                                           const float (&sc)[VEC], const float (&sh)[VEC], float (&m)[VEC],
+                                           int (&am)[VEC]) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = 255; }
+  for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; am[j] = 255; }
+  auto visit = [&](const Vec16<T>& v, int code) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float f = v.get(j);
+      if (BN) f = to_float(from_float<T>(fmaxf(f * sc[j] + sh[j], 0.f)));
+      if (f > m[j] || f != f || am[j] == 255) { m[j] = f; am[j] = code; }
+    }
+  };
+  if constexpr (KH > 0) {
+    Vec16<T> v[KH * KW];
+    bool ok[KH * KW];
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+      for (int q = 0; q < KW; ++q) {
+        const int iy = oy * g.sh - g.ph + r, ix = ox * g.sw - g.pw + q;
+        ok[r * KW + q] = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+        const int cy = min(max(iy, 0), g.IH - 1), cx = min(max(ix, 0), g.IW - 1);
+        v[r * KW + q].load(x + (((size_t)n * g.IH + cy) * g.IW + cx) * g.C + c * VEC);
+      }
+#pragma unroll
+    for (int t = 0; t < KH * KW; ++t)
+      if (ok[t]) visit(v[t], t);
+  } else {
     for (int r = 0; r < g.kh; ++r) {
       const int iy = oy * g.sh - g.ph + r;
       if ((unsigned)iy >= (unsigned)g.IH) continue;
@@ -37,13 +55,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         if ((unsigned)ix >= (unsigned)g.IW) continue;
         Vec16<T> v;
         v.load(x + (((size_t)n * g.IH + iy) * g.IW + ix) * g.C + c * VEC);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const float f = v.get(j);
-          if (f > m[j] || f != f || am[j] == 255) { m[j] = f; am[j] = r * g.kw + q; }
-        }
+        visit(v, r * g.kw + q);
       }
     }
+  }
+}
+
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, PoolGeom g, long total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cc = g.C / VEC;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float none[VEC] = {};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cc);
+    long pix = i / cc;
+    const int ox = (int)(pix % g.OW); pix /= g.OW;
+    const int oy = (int)(pix % g.OH);
+    const int n = (int)(pix / g.OH);
+    float m[VEC];
+    int am[VEC];
+    window_max<T, VEC, KH, KW, false>(x, g, (uint32_t)n, oy, ox, c, none, none, m, am);
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o.set(j, m[j]);
@@ -55,7 +88,62 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T>
+// Gradient arriving at input position (n, iy, ix), channels c*VEC..: sum of dy over the windows whose arg-max is
+// here, in ascending (oy, ox) order.  NW > 0: at most NW windows per axis contain a pixel (kernel <= NW * stride);
+// all NW*NW candidates are loaded up front from clamped addresses.  NW == 0: runtime-bounded loops.
+template <typename T, int VEC, int NW>
+__device__ __forceinline__ void pooled_grad(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
+                                            const PoolGeom& g, uint32_t n, int iy, int ix, int c, float (&acc)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  auto add = [&](const Vec16<T>& d, const uint8_t (&am)[VEC], int code) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      if (am[j] == code) acc[j] += d.get(j);
+  };
+  auto load_codes = [&](size_t o, uint8_t (&am)[VEC]) {
+    if (VEC == 8) *reinterpret_cast<uint2*>(am) = *reinterpret_cast<const uint2*>(idx + o);
+    else *reinterpret_cast<uint32_t*>(am) = *reinterpret_cast<const uint32_t*>(idx + o);
+  };
+  if constexpr (NW > 0) {
+    const int oyh = (iy + g.ph) / g.sh, oxh = (ix + g.pw) / g.sw;      // last window that can contain the pixel
+    Vec16<T> d[NW * NW];
+    uint8_t am[NW * NW][VEC];
+    int code[NW * NW];
+#pragma unroll
+    for (int a = 0; a < NW; ++a)
+#pragma unroll
+      for (int b = 0; b < NW; ++b) {
+        const int oy = oyh - (NW - 1 - a), ox = oxh - (NW - 1 - b);
+        const int r = iy + g.ph - oy * g.sh, q = ix + g.pw - ox * g.sw;
+        const bool ok = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW && r < g.kh && q < g.kw;
+        code[a * NW + b] = ok ? r * g.kw + q : 254;                     // 254: no stored code (< 250) matches
+        const int cy = min(max(oy, 0), g.OH - 1), cx = min(max(ox, 0), g.OW - 1);
+        const size_t o = (((size_t)n * g.OH + cy) * g.OW + cx) * g.C + c * VEC;
+        d[a * NW + b].load(dy + o);
+        load_codes(o, am[a * NW + b]);
+      }
+#pragma unroll
+    for (int t = 0; t < NW * NW; ++t) add(d[t], am[t], code[t]);
+  } else {
+    int oy_lo = (iy + g.ph - g.kh + g.sh) / g.sh; if (iy + g.ph - g.kh + 1 <= 0) oy_lo = 0;
+    int ox_lo = (ix + g.pw - g.kw + g.sw) / g.sw; if (ix + g.pw - g.kw + 1 <= 0) ox_lo = 0;
+    const int oy_hi = min(g.OH - 1, (iy + g.ph) / g.sh);
+    const int ox_hi = min(g.OW - 1, (ix + g.pw) / g.sw);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const int code = (iy - (oy * g.sh - g.ph)) * g.kw + (ix - (ox * g.sw - g.pw));
+        const size_t o = (((size_t)n * g.OH + oy) * g.OW + ox) * g.C + c * VEC;
+        Vec16<T> d;
+        d.load(dy + o);
+        uint8_t am[VEC];
+        load_codes(o, am);
+        add(d, am, code);
+      }
+  }
+}
+
+template <typename T, int NW>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
                                                           T* __restrict__ dx, PoolGeom g, long total) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -68,30 +156,145 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
     const int iy = (int)(pix % g.IH);
     const int n = (int)(pix / g.IH);
     float acc[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    // output windows that contain (iy, ix)
-    int oy_lo = (iy + g.ph - g.kh + g.sh) / g.sh; if (iy + g.ph - g.kh + 1 <= 0) oy_lo = 0;
-    int ox_lo = (ix + g.pw - g.kw + g.sw) / g.sw; if (ix + g.pw - g.kw + 1 <= 0) ox_lo = 0;
-    const int oy_hi = min(g.OH - 1, (iy + g.ph) / g.sh);
-    const int ox_hi = min(g.OW - 1, (ix + g.pw) / g.sw);
-    for (int oy = oy_lo; oy <= oy_hi; ++oy)
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        const int code = (iy - (oy * g.sh - g.ph)) * g.kw + (ix - (ox * g.sw - g.pw));
-        const size_t o = (((size_t)n * g.OH + oy) * g.OW + ox) * g.C + c * VEC;
-        Vec16<T> d;
-        d.load(dy + o);
-        uint8_t am[VEC];
-        if (VEC == 8) *reinterpret_cast<uint2*>(am) = *reinterpret_cast<const uint2*>(idx + o);
-        else *reinterpret_cast<uint32_t*>(am) = *reinterpret_cast<const uint32_t*>(idx + o);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          if (am[j] == code) acc[j] += d.get(j);
-      }
+    pooled_grad<T, VEC, NW>(idx, dy, g, (uint32_t)n, iy, ix, c, acc);
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o.set(j, acc[j]);
     o.store(dx + i * VEC);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem fusion: y = maxpool(relu(scale * x + shift)) where x is the stem convolution's output.  The
+// normalised full-resolution tensor (the largest activation of a ResNet: N x 112 x 112 x 64) is never
+// written: forward reads x once and writes the pooled tensor + arg-max codes; backward gathers the pooled
+// gradient through the codes on the fly, both for the BatchNorm reduction and for dx = A*g + B*x + K.
+// Every thread keeps ONE channel chunk (the launch makes gridDim.x * 256 a multiple of C / VEC).
+struct FusedGeom {
+  PoolGeom g;
+  FastDiv div_ohow, div_ow, div_ihiw, div_iw;
+};
+
+template <int VEC> __device__ __forceinline__ void load_vec(const float* __restrict__ p, int c0, float (&o)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + c0 + j);
+    o[j] = v.x; o[j + 1] = v.y; o[j + 2] = v.z; o[j + 3] = v.w;
+  }
+}
+
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                  uint8_t* __restrict__ idx,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, FusedGeom fg,
+                                                                  long total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const PoolGeom& g = fg.g;
+  const int cc = g.C / VEC;
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cc);
+  float sc[VEC], sh[VEC];
+  load_vec<VEC>(scale, c * VEC, sc);
+  load_vec<VEC>(shift, c * VEC, sh);
+  for (; i < total; i += stride) {
+    const uint32_t pix = (uint32_t)(i / cc);
+    const uint32_t n = fdiv(pix, fg.div_ohow);
+    const uint32_t rem = pix - n * fg.div_ohow.d;
+    const int oy = (int)fdiv(rem, fg.div_ow);
+    const int ox = (int)(rem - (uint32_t)oy * fg.div_ow.d);
+    float m[VEC];
+    int am[VEC];
+    // values rounded exactly like the stand-alone BN pass, so fused and unfused runs pick the same arg-max
+    window_max<T, VEC, KH, KW, true>(x, g, n, oy, ox, c, sc, sh, m, am);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, m[j]);
+    o.store(y + i * VEC);
+    uint8_t code[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) code[j] = (uint8_t)am[j];
+    if (VEC == 8) *reinterpret_cast<uint2*>(idx + i * VEC) = *reinterpret_cast<const uint2*>(code);
+    else *reinterpret_cast<uint32_t*>(idx + i * VEC) = *reinterpret_cast<const uint32_t*>(code);
+  }
+}
+
+// MODE 0: partial[block][2][C] = (sum g_m, sum g_m * xhat) over this block's pixels (g_m: pooled gradient, ReLU
+// masked).  MODE 1: dx = A*g_m + B*x + K with coef = [A | B | K] (bn_bwd_fold_finalize's work array).
+template <typename T, int MODE, int NW>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const uint8_t* __restrict__ idx,
+                                                                  const T* __restrict__ dyp, const T* __restrict__ x,
+                                                                  const float* __restrict__ bn /* mean,invstd,scale,shift */,
+                                                                  const float* __restrict__ coef, T* __restrict__ dx,
+                                                                  float* __restrict__ partial, FusedGeom fg, long total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float red[MODE == 0 ? 2 : 1][MODE == 0 ? 256 * VEC : 1];
+  const PoolGeom& g = fg.g;
+  const int C = g.C, cc = C / VEC;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int tid = threadIdx.x;
+  long i = (long)blockIdx.x * blockDim.x + tid;
+  const int c = (int)(i % cc);           // fixed for the thread: stride % cc == 0
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC], ca[VEC], cb[VEC], ck[VEC], s1[VEC], s2[VEC];
+  load_vec<VEC>(bn + 2 * C, c * VEC, sc);
+  load_vec<VEC>(bn + 3 * C, c * VEC, sh);
+  if (MODE == 0) {
+    load_vec<VEC>(bn, c * VEC, mu);
+    load_vec<VEC>(bn + C, c * VEC, is);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+  } else {
+    load_vec<VEC>(coef, c * VEC, ca);
+    load_vec<VEC>(coef + C, c * VEC, cb);
+    load_vec<VEC>(coef + 2 * C, c * VEC, ck);
+  }
+  for (; i < total; i += stride) {
+    const uint32_t pix = (uint32_t)(i / cc);
+    const uint32_t n = fdiv(pix, fg.div_ihiw);
+    const uint32_t rem = pix - n * fg.div_ihiw.d;
+    const int iy = (int)fdiv(rem, fg.div_iw);
+    const int ix = (int)(rem - (uint32_t)iy * fg.div_iw.d);
+    Vec16<T> vx;
+    vx.load(x + i * VEC);
+    float gr[VEC];
+    pooled_grad<T, VEC, NW>(idx, dyp, g, n, iy, ix, c, gr);
+    Vec16<T> vo;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float xv = vx.get(j);
+      float d = gr[j];
+      if (!(to_float(from_float<T>(sc[j] * xv + sh[j])) > 0.f)) d = 0.f;
+      else d = to_float(from_float<T>(d));      // the unfused path stores this gradient in T before BN reads it
+      if (MODE == 0) {
+        s1[j] += d;
+        s2[j] += d * ((xv - mu[j]) * is[j]);
+      } else {
+        vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
+      }
+    }
+    if (MODE == 1) vo.store(dx + i * VEC);
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      red[0][tid * VEC + j] = s1[j];
+      red[1][tid * VEC + j] = s2[j];
+    }
+    __syncthreads();
+    const int rp = 256 / cc;                 // threads per chunk column inside the block (tid % cc == column)
+    for (int t = tid; t < C; t += 256) {
+      const int cchunk = t / VEC, j = t - cchunk * VEC;
+      // the block's first thread sits at chunk column (blockIdx.x * 256) % cc == 0
+      float a1 = 0.f, a2 = 0.f;
+      for (int q = 0; q < rp; ++q) {
+        a1 += red[0][(q * cc + cchunk) * VEC + j];
+        a2 += red[1][(q * cc + cchunk) * VEC + j];
+      }
+      partial[((size_t)blockIdx.x * 2 + 0) * C + t] = a1;
+      partial[((size_t)blockIdx.x * 2 + 1) * C + t] = a2;
+    }
   }
 }
 
@@ -170,6 +373,8 @@ inline int grid_for(long n) {
   if (b > 256 * 16) b = 256 * 16;
   return (int)(b < 1 ? 1 : b);
 }
+// a pixel lies in at most 2 windows per axis (3x3 s2, 2x2 s2, 3x3 s2 ceil ...): the gather's fast path
+inline bool two_windows(int kh, int kw, int sh, int sw) { return kh <= 2 * sh && kw <= 2 * sw; }
 inline void check_c(int C, int dtype) {
   if (C % (dtype == kF32 ? 4 : 8) != 0) throw std::invalid_argument("pool: C must be a multiple of 16 bytes");
 }
@@ -182,8 +387,16 @@ void maxpool_fwd_launch(const void* x, void* y, uint8_t* idx, int NB, int IH, in
   PoolGeom g{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
   const long total = (long)NB * OH * OW * (C / (dtype == kF32 ? 4 : 8));
   if (total <= 0) return;
-  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
-                                               (const T*)x, (T*)y, idx, g, total));
+  if (kh == 3 && kw == 3) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 3, 3>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)x, (T*)y, idx, g, total));
+  } else if (kh == 2 && kw == 2) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 2, 2>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)x, (T*)y, idx, g, total));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T, 0, 0>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)x, (T*)y, idx, g, total));
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
@@ -192,10 +405,94 @@ void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, in
   PoolGeom g{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
   const long total = (long)NB * IH * IW * (C / (dtype == kF32 ? 4 : 8));
   if (total <= 0) return;
-  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
-                                               idx, (const T*)dy, (T*)dx, g, total));
+  if (two_windows(kh, kw, sh, sw)) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 2>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 idx, (const T*)dy, (T*)dx, g, total));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 0>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 idx, (const T*)dy, (T*)dx, g, total));
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
+namespace {
+FusedGeom fused_geom(int NB, int IH, int IW, int C, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw,
+                     int dtype) {
+  check_c(C, dtype);
+  const int cc = C / (dtype == kF32 ? 4 : 8);
+  if (256 % cc != 0) throw std::invalid_argument("fused BN+ReLU+maxpool: C / vector width must divide 256");
+  if ((long)NB * IH * IW >= (1l << 31) || kh * kw > 250)
+    throw std::invalid_argument("fused BN+ReLU+maxpool: problem too large");
+  FusedGeom fg;
+  fg.g = PoolGeom{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
+  fg.div_ohow = make_fastdiv((uint32_t)(OH * OW));
+  fg.div_ow = make_fastdiv((uint32_t)OW);
+  fg.div_ihiw = make_fastdiv((uint32_t)(IH * IW));
+  fg.div_iw = make_fastdiv((uint32_t)IW);
+  return fg;
+}
+}  // namespace
+
+int bn_relu_maxpool_partial_rows(long in_chunks) {
+  long b = (in_chunks + 256 * 8 - 1) / (256 * 8);     // >= 8 chunks per thread
+  if (b > 2048) b = 2048;
+  return (int)(b < 1 ? 1 : b);
+}
+
+void bn_relu_maxpool_fwd_launch(const void* x, void* y, uint8_t* idx, const float* scale, const float* shift, int NB,
+                                int IH, int IW, int C, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw,
+                                int dtype, hipStream_t s) {
+  const FusedGeom fg = fused_geom(NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype);
+  const long total = (long)NB * OH * OW * (C / (dtype == kF32 ? 4 : 8));
+  if (total <= 0) return;
+  if (kh == 3 && kw == 3) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T, 3, 3>), dim3(grid_for(total)), dim3(256),
+                                                 0, s, (const T*)x, (T*)y, idx, scale, shift, fg, total));
+  } else if (kh == 2 && kw == 2) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T, 2, 2>), dim3(grid_for(total)), dim3(256),
+                                                 0, s, (const T*)x, (T*)y, idx, scale, shift, fg, total));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T, 0, 0>), dim3(grid_for(total)), dim3(256),
+                                                 0, s, (const T*)x, (T*)y, idx, scale, shift, fg, total));
+  }
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_relu_maxpool_bwd_reduce_launch(const uint8_t* idx, const void* dyp, const void* x, const float* bn,
+                                       float* partial, int nblk, int NB, int IH, int IW, int C, int OH, int OW, int kh,
+                                       int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
+  const FusedGeom fg = fused_geom(NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype);
+  const long total = (long)NB * IH * IW * (C / (dtype == kF32 ? 4 : 8));
+  if (total <= 0 || nblk <= 0) return;
+  if (two_windows(kh, kw, sh, sw)) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<T, 0, 2>), dim3(nblk), dim3(256), 0, s, idx,
+                                                 (const T*)dyp, (const T*)x, bn, nullptr, (T*)nullptr, partial, fg,
+                                                 total));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<T, 0, 0>), dim3(nblk), dim3(256), 0, s, idx,
+                                                 (const T*)dyp, (const T*)x, bn, nullptr, (T*)nullptr, partial, fg,
+                                                 total));
+  }
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bn_relu_maxpool_bwd_apply_launch(const uint8_t* idx, const void* dyp, const void* x, const float* bn,
+                                      const float* coef, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
+                                      int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
+  const FusedGeom fg = fused_geom(NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw, dtype);
+  const long total = (long)NB * IH * IW * (C / (dtype == kF32 ? 4 : 8));
+  if (total <= 0) return;
+  if (two_windows(kh, kw, sh, sw)) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<T, 1, 2>), dim3(grid_for(total)), dim3(256),
+                                                 0, s, idx, (const T*)dyp, (const T*)x, bn, coef, (T*)dx, nullptr, fg,
+                                                 total));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_kernel<T, 1, 0>), dim3(grid_for(total)), dim3(256),
+                                                 0, s, idx, (const T*)dyp, (const T*)x, bn, coef, (T*)dx, nullptr, fg,
+                                                 total));
+  }
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
 void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW, int dtype,
                         hipStream_t s) {
   check_c(C, dtype);

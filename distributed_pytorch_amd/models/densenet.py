@@ -14,7 +14,8 @@ from typing import Tuple
 import torch
 from torch import nn
 
-from ..nn.modules import AdaptiveAvgPool2d, AvgPool2d, BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLU, conv_bn_act
+from ..nn.modules import (AdaptiveAvgPool2d, AvgPool2d, BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLU, conv_bn_act,
+                          conv_bn_relu_maxpool)
 from ..ops import functional as F
 from .alexnet_vgg import _ImageNetCNN
 
@@ -94,8 +95,7 @@ class DenseNet(_ImageNetCNN):
     def forward(self, x):
         x = self.prepare_input(x)
         f = self.features
-        x = conv_bn_act(x, f.conv0, f.norm0, relu=True)
-        x = f.pool0(x)
+        x = conv_bn_relu_maxpool(x, f.conv0, f.norm0, f.pool0)          # fused stem
         for name, m in f.named_children():
             if name.startswith("denseblock") or name.startswith("transition"):
                 x = m(x)

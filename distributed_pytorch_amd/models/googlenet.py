@@ -18,7 +18,8 @@ from collections import namedtuple
 import torch
 from torch import nn
 
-from ..nn.modules import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Dropout, Linear, MaxPool2d, conv_bn_act
+from ..nn.modules import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Dropout, Linear, MaxPool2d, conv_bn_act,
+                          conv_bn_relu_maxpool)
 from ..ops import functional as F
 from .alexnet_vgg import _ImageNetCNN
 
@@ -106,7 +107,7 @@ class GoogLeNet(_ImageNetCNN):
 
     def forward(self, x):
         x = self.prepare_input(x)
-        x = self.maxpool1(self.conv1(x))
+        x = conv_bn_relu_maxpool(x, self.conv1.conv, self.conv1.bn, self.maxpool1)      # fused stem
         x = self.maxpool2(self.conv3(self.conv2(x)))
         x = self.maxpool3(self.inception3b(self.inception3a(x)))
         x = self.inception4a(x)

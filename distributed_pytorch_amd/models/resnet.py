@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import amp
 from ..nn.modules import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLU,
-                          conv_bn_act)
+                          conv_bn_act, conv_bn_relu_maxpool)
 from ..ops import functional as F
 
 STEM_PAD_C = 8  # image channels 3 -> 8 on the GPU so every im2col chunk is one 16-byte vector
@@ -140,8 +140,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         x = self.prepare_input(x)
-        x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        x = self.maxpool(x)
+        x = conv_bn_relu_maxpool(x, self.conv1, self.bn1, self.maxpool)     # fused stem
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)                       # [N,1,1,C]
         x = x.reshape(x.shape[0], -1)

@@ -187,6 +187,18 @@ class Flatten(nn.Module):
         return x.reshape(x.shape[0], -1)
 
 
+def conv_bn_relu_maxpool(x, conv: Conv2d, bn: BatchNorm2d, pool: "MaxPool2d"):
+    """Stem: conv -> BN -> ReLU -> max-pool with the BN/ReLU/pool part as one fused pass (``F.bn_relu_max_pool2d``)."""
+    fuse = F._on_gpu(x) and bn.training and bn.process_group is None
+    out = conv(x, want_stats=fuse)
+    stats = None
+    if fuse:
+        out, stats = out
+    return F.bn_relu_max_pool2d(out, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                bn.training, bn.momentum, bn.eps, pool.kernel_size, pool.stride, pool.padding,
+                                pool.ceil_mode, stats=stats, group=bn.process_group)
+
+
 def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False):
     """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not

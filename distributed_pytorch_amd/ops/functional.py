@@ -124,6 +124,19 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
     return y.contiguous()
 
 
+def bn_relu_max_pool2d(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps,
+                       kernel_size, stride=None, padding=0, ceil_mode: bool = False, *, stats=None, group=None):
+    """``max_pool2d(relu(batch_norm(x)))`` -- the stem of ResNet / DenseNet / GoogLeNet.  On the GPU in training mode
+    (no SyncBN) this is the fused stem path: the normalised full-resolution tensor is never materialised."""
+    k, s, p = _pair(kernel_size), _pair(stride if stride is not None else kernel_size), _pair(padding)
+    if _on_gpu(x) and training and group is None and _hip().can_fuse_bn_relu_maxpool(x):
+        return _hip().bn_relu_maxpool(x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                      stats, k, s, p, ceil_mode)
+    y = batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps,
+                   relu=True, stats=stats, group=group)
+    return max_pool2d(y, k, s, p, ceil_mode)
+
+
 # ----------------------------------------------------------------------------- pooling
 def max_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, ceil_mode: bool = False) -> torch.Tensor:
     k, s, p = _pair(kernel_size), _pair(stride if stride is not None else kernel_size), _pair(padding)

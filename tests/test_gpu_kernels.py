@@ -478,3 +478,48 @@ def test_batch_norm_relu6(dtype, res, training):
         _close(b.grad, br.grad, dtype, scale=8, what="dbeta")
     if res:
         _close(r.grad.permute(0, 3, 1, 2), rr.grad, dtype, what="dres")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(3, 2, 1, False, 17, 19), (3, 2, 0, True, 16, 16), (2, 2, 0, False, 12, 10)])
+def test_fused_bn_relu_maxpool_stem(dtype, geom):
+    """BN + ReLU + max-pool in one pass (never writes the normalised tensor) == the three separate kernels,
+    bit for bit in the outputs / running statistics and to rounding in the gradients, == the torch reference."""
+    from distributed_pytorch_amd.ops import hip_ops
+    k, s, p, ceil, H, W = geom
+    torch.manual_seed(6)
+    N, C = 3, 64
+    x0 = (torch.randn(N, H, W, C, device=DEV) * 1.5 + 0.3).to(dtype)
+    g0 = torch.rand(C, device=DEV) + 0.5
+    b0 = torch.randn(C, device=DEV) * 0.3
+    outs = []
+    for fused in (True, False):
+        hip_ops._FUSE_STEM = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            g, b = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            nbt = torch.zeros((), dtype=torch.long, device=DEV)
+            y = F.bn_relu_max_pool2d(x, g, b, rm, rv, nbt, True, 0.1, 1e-5, k, s, p, ceil)
+            if fused:
+                assert type(y.grad_fn).__name__ == "_BNReluMaxPoolFnBackward"
+                gy = torch.randn_like(y.float()).to(dtype)
+            y.backward(gy)
+            outs.append((y.detach(), x.grad, g.grad, b.grad, rm, rv, int(nbt.item())))
+        finally:
+            hip_ops._FUSE_STEM = True
+    (yf, dxf, dgf, dbf, rmf, rvf, nf), (yu, dxu, dgu, dbu, rmu, rvu, nu) = outs
+    assert torch.equal(yf, yu) and torch.equal(rmf, rmu) and torch.equal(rvf, rvu) and nf == nu == 1
+    _close(dxf, dxu, dtype, what="dx fused vs unfused")
+    _close(dgf, dgu, dtype, scale=2, what="dgamma fused vs unfused")
+    _close(dbf, dbu, dtype, scale=2, what="dbeta fused vs unfused")
+    # torch reference on the same (rounded) inputs
+    xr = x0.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = TF.max_pool2d(TF.relu(TF.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)), k, s, p, ceil_mode=ceil)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(yf.permute(0, 3, 1, 2), yr, dtype, what="y")
+    if dtype == torch.float32:        # low precision: rounding can move an arg-max between tied neighbours
+        _close(dxf.permute(0, 3, 1, 2), xr.grad, dtype, scale=2, what="dx")
+        _close(dgf, gr.grad, dtype, scale=4, what="dgamma")
+        _close(dbf, br.grad, dtype, scale=4, what="dbeta")
