@@ -91,8 +91,10 @@ def main():
     total = args.steps + args.warmup + 2
     data = SyntheticImageNet(args.batch_size, world_size=world, rank=rank, image_size=args.image_size,
                              steps=total)
+    base = getattr(model, "module", model)
     pre = StreamPrefetcher(data, device, dtype=amp.compute_dtype(torch.float32),
-                           pad_c=0 if F._TORCH_BASELINE else 8)
+                           pad_c=0 if F._TORCH_BASELINE else 8,
+                           s2d=bool(getattr(base, "stem_s2d", False)) and not F._TORCH_BASELINE)
 
     graphed = None
     if args.graph and world == 1 and not F._TORCH_BASELINE:

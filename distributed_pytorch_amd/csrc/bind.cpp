@@ -233,6 +233,11 @@ PYBIND11_MODULE(_C, m) {
     normalize_u8_launch(ptr<const uint8_t>(x), ptr<void>(y), npix, cin, cout, hw, nchw, ptr<const float>(mean),
                         ptr<const float>(istd), dtype, st(s));
   });
+  m.def("to_s2d", [](uintptr_t x, uintptr_t y, int NB, int H2, int W2, int nchw, int in_dtype, uintptr_t mean,
+                     uintptr_t inv_std, int out_dtype, uintptr_t s) {
+    to_s2d_launch(ptr<const void>(x), ptr<void>(y), NB, H2, W2, nchw, in_dtype, ptr<const float>(mean),
+                  ptr<const float>(inv_std), out_dtype, st(s));
+  });
   m.def("nchw_to_nhwc", [](uintptr_t x, uintptr_t y, int NB, int C, int HW, int cpad, int in_dtype, int out_dtype,
                            uintptr_t s) {
     nchw_to_nhwc_launch(ptr<const void>(x), ptr<void>(y), NB, C, HW, cpad, in_dtype, out_dtype, st(s));

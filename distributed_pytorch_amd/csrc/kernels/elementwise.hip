@@ -41,6 +41,48 @@ __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __rest
   }
 }
 
+// Space-to-depth image layout for 7x7 stride-2 stems: [N][H][W][3] (or NCHW) -> [N][H/2][W/2][16] where channel
+// (py*2 + px)*3 + c holds pixel (2Y+py, 2X+px), channels 12..15 are zero.  The stem then is a 4x4 stride-1
+// convolution over 16 channels (K = 256 instead of 7*7*8 = 392 with channel padding) on a tensor half the size.
+// U8: (x - 255*mean_c) / (255*std_c) (the prefetcher's normalisation); otherwise a plain conversion.
+template <typename TI, typename TO, bool U8>
+__global__ __launch_bounds__(256) void to_s2d_kernel(const TI* __restrict__ x, TO* __restrict__ y, int NB, int H2, int W2,
+                                                     int nchw, const float* __restrict__ mean255,
+                                                     const float* __restrict__ inv_std255) {
+  constexpr int VEC = 16 / (int)sizeof(TO);
+  constexpr int CH = 16 / VEC;                       // chunks per s2d pixel
+  const long total = (long)NB * H2 * W2 * CH;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int H = 2 * H2, W = 2 * W2;
+  float mu[3] = {0.f, 0.f, 0.f}, is[3] = {1.f, 1.f, 1.f};
+  if (U8) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { mu[c] = mean255[c]; is[c] = inv_std255[c]; }
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int h = (int)(i % CH);
+    long pix = i / CH;
+    const int X = (int)(pix % W2); pix /= W2;
+    const int Y = (int)(pix % H2);
+    const long n = pix / H2;
+    Vec16<TO> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int ch = h * VEC + j;
+      float v = 0.f;
+      if (ch < 12) {
+        const int q = ch / 3, c = ch - q * 3;
+        const int iy = 2 * Y + (q >> 1), ix = 2 * X + (q & 1);
+        const long src = nchw ? ((n * 3 + c) * H + iy) * W + ix : ((n * H + iy) * W + ix) * 3 + c;
+        if constexpr (U8) v = ((float)x[src] - mu[c]) * is[c];
+        else v = to_float(x[src]);
+      }
+      o.set(j, v);
+    }
+    o.store(y + i * VEC);
+  }
+}
+
 // float-ish NCHW -> NHWC with channel padding (LDS-free: C is tiny (3) for images)
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y, int NB, int C,
@@ -199,6 +241,23 @@ void normalize_u8_launch(const uint8_t* x, void* y, long npix, int cin, int cout
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(normalize_u8_kernel<T>, dim3(grid_for(npix * (cout / (16 / (int)sizeof(T))))),
                                                dim3(256), 0, s, x, (T*)y, npix, cin, cout, hw, nchw, mean255,
                                                inv_std255));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void to_s2d_launch(const void* x, void* y, int NB, int H2, int W2, int nchw, int in_dtype, const float* mean255,
+                   const float* inv_std255, int out_dtype, hipStream_t s) {
+  const long total = (long)NB * H2 * W2 * (out_dtype == kF32 ? 4 : 2);
+  if (total <= 0) return;
+  if (in_dtype < 0) {      // uint8 source
+    if (mean255 == nullptr || inv_std255 == nullptr) throw std::invalid_argument("to_s2d: uint8 input needs mean / std");
+    DPA_DISPATCH_DTYPE(out_dtype, hipLaunchKernelGGL((to_s2d_kernel<uint8_t, T, true>), dim3(grid_for(total)), dim3(256),
+                                                     0, s, (const uint8_t*)x, (T*)y, NB, H2, W2, nchw, mean255,
+                                                     inv_std255));
+  } else {
+    DPA_DISPATCH_2(in_dtype, out_dtype,
+                   hipLaunchKernelGGL((to_s2d_kernel<TI, TO, false>), dim3(grid_for(total)), dim3(256), 0, s,
+                                      (const TI*)x, (TO*)y, NB, H2, W2, nchw, nullptr, nullptr));
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 

@@ -21,8 +21,9 @@ from ..ops import functional as F
 
 class StreamPrefetcher:
     def __init__(self, loader, device: torch.device, dtype: torch.dtype = torch.float32,
-                 pad_c: int = 0, normalize: bool = True):
+                 pad_c: int = 0, normalize: bool = True, s2d: bool = False):
         self.loader = iter(loader)
+        self.s2d = s2d      # the model's stem takes the space-to-depth layout (model.stem_s2d): emit it directly
         self.device, self.dtype, self.pad_c, self.normalize = device, dtype, pad_c, normalize
         self.on_gpu = device.type == "cuda"
         self.stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device) if self.on_gpu else None
@@ -34,6 +35,8 @@ class StreamPrefetcher:
         images = images.to(self.device, non_blocking=True)
         target = target.to(self.device, non_blocking=True)
         if images.dtype == torch.uint8 and self.normalize:
+            if self.s2d and F.s2d_ok(images):
+                return F.to_s2d(images, self.dtype), target        # tagged _dpa_s2d / _dpa_nhwc
             layout = "nhwc" if images.shape[-1] in (1, 3) else "nchw"
             images = F.normalize_u8(images, self.dtype, self.pad_c, input_layout=layout)
             images._dpa_nhwc = True

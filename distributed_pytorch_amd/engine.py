@@ -288,8 +288,10 @@ class _Run:
             self.jsonl = open(os.path.join(args.out_dir, "metrics.jsonl"), "a")
 
     def _prefetcher(self, loader):
+        base = getattr(self.model, "module", self.model)
         return StreamPrefetcher(loader, self.device, dtype=amp.compute_dtype(torch.float32),
-                                pad_c=8 if F._on_gpu(torch.empty(0, device=self.device)) else 0)
+                                pad_c=8 if F._on_gpu(torch.empty(0, device=self.device)) else 0,
+                                s2d=bool(getattr(base, "stem_s2d", False)))
 
     def _reduced(self, packed: torch.Tensor) -> torch.Tensor:
         """APX averages metrics over ranks (``reduce_tensor``), nd/ddp report rank-local values."""

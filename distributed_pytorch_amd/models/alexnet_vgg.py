@@ -49,9 +49,15 @@ def run_fused_sequential(seq: nn.Sequential, x, final_dtype=None):
 
 
 class _ImageNetCNN(nn.Module):
+    stem_s2d = False     # True for 7x7 stride-2 pad-3 stems: the space-to-depth image layout (F.to_s2d)
+
     def prepare_input(self, x):
         dtype = amp.compute_dtype(torch.float32)
         pad = STEM_PAD_C if F._on_gpu(x) else 0
+        if getattr(x, "_dpa_nhwc", False):      # already normalised (StreamPrefetcher)
+            return x
+        if self.stem_s2d and F.s2d_ok(x):
+            return F.to_s2d(x, dtype)
         if x.dtype == torch.uint8:
             layout = "nhwc" if x.shape[-1] in (1, 3) else "nchw"
             return F.normalize_u8(x, dtype, pad, input_layout=layout)

@@ -62,6 +62,7 @@ class _Transition(nn.Sequential):
 
 
 class DenseNet(_ImageNetCNN):
+    stem_s2d = True
     def __init__(self, growth_rate: int = 32, block_config: Tuple[int, ...] = (6, 12, 24, 16),
                  num_init_features: int = 64, bn_size: int = 4, num_classes: int = 1000):
         super().__init__()

@@ -69,6 +69,7 @@ class InceptionAux(nn.Module):
 
 
 class GoogLeNet(_ImageNetCNN):
+    stem_s2d = True
     def __init__(self, num_classes: int = 1000, aux_logits: bool = False, dropout: float = 0.2,
                  dropout_aux: float = 0.7):
         super().__init__()

@@ -126,11 +126,17 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes, base_width=self.base_width, groups=self.groups))
         return nn.Sequential(*layers)
 
+    stem_s2d = True      # 7x7 stride-2 pad-3 stem: takes the space-to-depth image layout on the GPU (F.to_s2d)
+
     def prepare_input(self, x: torch.Tensor) -> torch.Tensor:
         """Accepts torchvision-style float NCHW, or uint8 (NHWC/NCHW) straight from
         the prefetcher; returns normalised NHWC in the compute dtype."""
         dtype = amp.compute_dtype(torch.float32)
         pad = STEM_PAD_C if F._on_gpu(x) else 0
+        if getattr(x, "_dpa_nhwc", False):
+            return x
+        if self.stem_s2d and F.s2d_ok(x):
+            return F.to_s2d(x, dtype)
         if x.dtype == torch.uint8:
             layout = "nhwc" if x.shape[-1] in (1, 3) else "nchw"
             return F.normalize_u8(x, dtype, pad, input_layout=layout)

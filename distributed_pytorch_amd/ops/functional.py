@@ -53,6 +53,10 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     ``groups > 1``: grouped / depthwise convolution, every pass one launch with the group on ``grid.y``.
     """
     stride, padding = _pair(stride), _pair(padding)
+    if getattr(x, "_dpa_s2d", False):       # space-to-depth image (to_s2d): the 7x7 stride-2 stem as a 4x4 convolution
+        if groups != 1 or skip or not _on_gpu(x):
+            raise ValueError("space-to-depth input is only valid for a dense GPU stem convolution")
+        return _hip().stem_s2d_conv(x, weight, bias, stride, padding, relu, want_stats)
     if groups > 1:
         if _on_gpu(x):
             out = _hip().group_conv2d(x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad)
@@ -267,6 +271,17 @@ def normalize_u8(x: torch.Tensor, dtype: torch.dtype = torch.float32, pad_c: int
     if pad_c and pad_c > y.shape[-1]:
         y = TF.pad(y, (0, pad_c - y.shape[-1]))
     return y.contiguous()
+
+
+def s2d_ok(x: torch.Tensor) -> bool:
+    """True when ``to_s2d`` applies: a 3-channel image batch with even extents on the GPU."""
+    return _on_gpu(x) and _hip().s2d_ok(x)
+
+
+def to_s2d(x: torch.Tensor, dtype: torch.dtype, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """Image batch (uint8 NHWC / NCHW: normalised like ``normalize_u8``; float NCHW: converted) -> the space-to-depth
+    layout ``[N, H/2, W/2, 16]`` consumed by 7x7 stride-2 stems (ResNet, DenseNet, GoogLeNet).  GPU only."""
+    return _hip().to_s2d(x, dtype, mean, std)
 
 
 def to_nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_c: int = 0) -> torch.Tensor:

@@ -1375,6 +1375,144 @@ def normalize_u8(x, dtype, pad_c, mean, std, input_layout):
     return y
 
 
+# ------------------------------------------------------------------------------------------
+# space-to-depth stem: 7x7 stride-2 pad-3 convolution of a 3-channel image == 4x4 stride-1 convolution (taps
+# -2..1) of the [N, H/2, W/2, 16] space-to-depth image.  K = 256 instead of 7*7*8 = 392, input tensor half the size.
+# ------------------------------------------------------------------------------------------
+_STEM_S2D = os.environ.get("DPA_STEM_S2D", "1") == "1"
+_S2D_TAPS = tuple((ty - 2, tx - 2, ty * 4 + tx) for ty in range(4) for tx in range(4))
+_s2d_idx: Dict[int, torch.Tensor] = {}
+
+
+def s2d_ok(x) -> bool:
+    """Image batch (uint8 NHWC/NCHW or float NCHW) with 3 channels and even extents."""
+    if not _STEM_S2D or x.dim() != 4:
+        return False
+    if x.dtype == torch.uint8 and x.shape[-1] == 3:
+        H, W = x.shape[1], x.shape[2]
+    elif x.shape[1] == 3:
+        H, W = x.shape[2], x.shape[3]
+    else:
+        return False
+    return H % 2 == 0 and W % 2 == 0 and H >= 2 and W >= 2
+
+
+def to_s2d(x, dtype, mean, std):
+    x = x if x.is_contiguous() else x.contiguous()
+    nhwc = x.dtype == torch.uint8 and x.shape[-1] == 3
+    if nhwc:
+        NB, H, W, _ = x.shape
+    else:
+        NB, _, H, W = x.shape
+    y = torch.empty((NB, H // 2, W // 2, 16), dtype=dtype, device=x.device)
+    if x.dtype == torch.uint8:
+        key = (x.device.index, tuple(mean), tuple(std))
+        if key not in _norm_consts:
+            m = torch.tensor([v * 255.0 for v in mean], dtype=torch.float32, device=x.device)
+            s = torch.tensor([1.0 / (v * 255.0) for v in std], dtype=torch.float32, device=x.device)
+            _norm_consts[key] = (m, s)
+        m, s = _norm_consts[key]
+        C().to_s2d(x.data_ptr(), y.data_ptr(), NB, H // 2, W // 2, 0 if nhwc else 1, -1, m.data_ptr(), s.data_ptr(),
+                   _dt(dtype), _stream())
+    else:
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            x = x.float()
+        C().to_s2d(x.data_ptr(), y.data_ptr(), NB, H // 2, W // 2, 1, _dt(x), 0, 0, _dt(dtype), _stream())
+    y._dpa_s2d = True
+    y._dpa_nhwc = True
+    return y
+
+
+def _s2d_index(device) -> torch.Tensor:
+    """Position of w[k, c, r, s] (flattened (r, s, c)) inside the [16 taps][16 channels] row of the s2d filter."""
+    t = _s2d_idx.get(device.index)
+    if t is None:
+        idx = [(((r + 1) // 2) * 4 + (s + 1) // 2) * 16 + (((r + 1) % 2) * 2 + (s + 1) % 2) * 3 + c
+               for r in range(7) for s in range(7) for c in range(3)]
+        t = torch.tensor(idx, dtype=torch.int64, device=device)
+        _s2d_idx[device.index] = t
+    return t
+
+
+def stem_weight_s2d(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    K = w.shape[0]
+    c = _cache(w)
+    key = (dtype, "s2d")
+    if c.wc is not None and c.wc_key == key and c.wc_stamp == _stamp(w):
+        return c.wc
+    if c.wc is None or c.wc_key != key:
+        c.wc = torch.zeros((K, 256), dtype=dtype, device=w.device)
+    c.wc[:, _s2d_index(w.device)] = w.detach().permute(0, 2, 3, 1).reshape(K, 147).to(dtype)
+    c.wc_key, c.wc_stamp = key, _stamp(w)
+    return c.wc
+
+
+class _StemS2DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, want_stats):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, H2, W2, Cx = x.shape
+        K = weight.shape[0]
+        if Cx != 16 or tuple(weight.shape[1:]) != (3, 7, 7):
+            raise ValueError("space-to-depth stem needs a [N, H/2, W/2, 16] input and a [K, 3, 7, 7] filter")
+        w2 = stem_weight_s2d(weight, x.dtype)
+        M = NB * H2 * W2
+        y = torch.empty((NB, H2, W2, K), dtype=x.dtype, device=x.device)
+        stats = None
+        if want_stats:
+            tiles = C().igemm_stats_rows(M, K, 16, 16, _dt(x), _dt(x))
+            stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+        taps = _tap_table(x.device, _S2D_TAPS)
+        bias_f = None
+        if bias is not None:
+            bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
+        _igemm(x, w2, y, bias_f, stats, taps, M, K, 16, 16, 16, 256, K, H2, W2, 1, 1, H2, W2, relu=relu,
+               dtype=x.dtype, out_dtype=x.dtype)
+        ctx.cfg = (relu, bias is not None)
+        ctx.bias_ref = bias
+        ctx.save_for_backward(x, weight, y if relu else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, dstats=None):
+        x, weight, y = ctx.saved_tensors
+        relu, has_bias = ctx.cfg
+        NB, H2, W2, _ = x.shape
+        K = weight.shape[0]
+        M = NB * H2 * W2
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        st = _stream()
+        if relu:
+            dym = torch.empty_like(dy)
+            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
+            dy = dym
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            splits, pps = C().wgrad_choose_splits(M, K, 256, _dt(dy))
+            slab = torch.empty((splits, K, 256), dtype=torch.float32, device=dy.device)
+            taps = _tap_table(dy.device, _S2D_TAPS)
+            C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, 16, 16, K, 16, H2, W2, 1, 1,
+                      H2, W2, splits, pps, 0, _dt(dy), st)
+            full = torch.empty((K, 256), dtype=torch.float32, device=dy.device)
+            C().slab_reduce(slab.data_ptr(), splits, K * 256, full.data_ptr(), 0, 0.0, st)
+            g = full[:, _s2d_index(dy.device)].view(K, 7, 7, 3).permute(0, 3, 1, 2)
+            dw = _deliver(weight, g.to(weight.dtype))
+        if has_bias and ctx.needs_input_grad[2]:
+            bias_p = ctx.bias_ref
+            db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
+        return None, dw, db, None, None
+
+
+def stem_s2d_conv(x, weight, bias, stride, padding, relu, want_stats):
+    if tuple(stride) != (2, 2) or tuple(padding) != (3, 3):
+        raise ValueError("space-to-depth input reached a convolution that is not a 7x7 stride-2 pad-3 stem")
+    grad_sink.note_use(weight, bias)
+    y, stats = _StemS2DFn.apply(x, weight, bias, bool(relu), bool(want_stats))
+    return (y, stats) if want_stats else y
+
+
 def nchw_to_nhwc(x, dtype, pad_c):
     x = x if x.is_contiguous() else x.contiguous()
     NB, Cc, H, W = x.shape

@@ -51,6 +51,8 @@ class GraphedTrainStep:
         self.static_t = target.clone()
         if getattr(images, "_dpa_nhwc", False):      # the prefetcher's "already normalised NHWC" tag
             self.static_x._dpa_nhwc = True
+        if getattr(images, "_dpa_s2d", False):       # ... and its space-to-depth stem layout
+            self.static_x._dpa_s2d = True
         sync = getattr(self.optimizer, "sync_hyper", None)
         if sync is not None:
             sync()
@@ -64,7 +66,7 @@ class GraphedTrainStep:
     @staticmethod
     def _key(images, target):
         return (tuple(images.shape), images.dtype, tuple(target.shape), target.dtype,
-                bool(getattr(images, "_dpa_nhwc", False)))
+                bool(getattr(images, "_dpa_nhwc", False)), bool(getattr(images, "_dpa_s2d", False)))
 
     def __call__(self, images, target):
         if not self.enabled or not images.is_cuda:

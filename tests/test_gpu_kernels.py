@@ -523,3 +523,43 @@ def test_fused_bn_relu_maxpool_stem(dtype, geom):
         _close(dxf.permute(0, 3, 1, 2), xr.grad, dtype, scale=2, what="dx")
         _close(dgf, gr.grad, dtype, scale=4, what="dgamma")
         _close(dbf, br.grad, dtype, scale=4, what="dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("src", ["u8_nhwc", "u8_nchw", "float_nchw"])
+def test_space_to_depth_stem(dtype, src):
+    """7x7 stride-2 pad-3 stem as a 4x4 convolution over the space-to-depth image (F.to_s2d): forward, fused
+    statistics and the weight gradient (mapped back to [K, 3, 7, 7]) against torch's conv2d on the same pixels."""
+    torch.manual_seed(8)
+    N, H, W, K = 3, 20, 28, 64
+    mean, std = F.IMAGENET_MEAN, F.IMAGENET_STD
+    if src == "float_nchw":
+        img = torch.randn(N, 3, H, W, device=DEV)
+        ref_in = img.to(dtype).float()
+        xs = F.to_s2d(img, dtype)
+    else:
+        u8 = torch.randint(0, 256, (N, H, W, 3), dtype=torch.uint8, device=DEV)
+        m = torch.tensor(mean, device=DEV) * 255
+        s = torch.tensor(std, device=DEV) * 255
+        ref_in = ((u8.float() - m) / s).to(dtype).float().permute(0, 3, 1, 2)
+        xs = F.to_s2d(u8 if src == "u8_nhwc" else u8.permute(0, 3, 1, 2).contiguous(), dtype)
+    assert xs.shape == (N, H // 2, W // 2, 16) and xs._dpa_s2d and bool((xs[..., 12:] == 0).all())
+    # channel (py*2+px)*3+c of s2d pixel (Y, X) is image pixel (2Y+py, 2X+px)
+    _close(xs[:, 3, 5, 9:12], ref_in[:, :, 7, 11], dtype, scale=0.01 if dtype == torch.float32 else 1.0, what="layout")
+    w = (torch.randn(K, 3, 7, 7, device=DEV) / 12).requires_grad_(True)
+    b = torch.randn(K, device=DEV).requires_grad_(True)
+    y, stats = F.conv2d(xs, w, b, 2, 3, relu=True, want_stats=True, needs_input_grad=False)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    yr = TF.conv2d(ref_in, wr, br, 2, 3)
+    mask = y.detach().permute(0, 3, 1, 2) > 0
+    assert (mask != (yr.detach() > 0)).float().mean().item() < 2e-3
+    yr = yr * mask
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype, what="fprop")
+    yf = y.detach().float().reshape(-1, K)
+    _close(stats.sum(0)[0], yf.sum(0), torch.float32, scale=10, what="stats")
+    _close(w.grad, wr.grad, dtype, scale=2, what="wgrad")
+    _close(b.grad, br.grad, dtype, scale=2, what="bias grad")
