@@ -61,6 +61,8 @@ PYBIND11_MODULE(_C, m) {
         py::arg("bn_coef") = 0, py::arg("bn_relu") = 0, py::arg("groups") = 1, py::arg("a_gstride") = 0,
         py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
+  m.attr("IGEMM_ROW3") = (int)kIgemmRow3;
+  m.def("igemm_set_row3", &igemm_set_row3);
   m.def("igemm_tile_m", &igemm_tile_m);
   m.def("igemm_stats_rows", &igemm_stats_rows);
   m.def("igemm_force_config", &igemm_force_config);

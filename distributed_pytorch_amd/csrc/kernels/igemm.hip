@@ -439,6 +439,211 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Filter-row kernel for 3x3-like stride-1 "same" convolutions (kIgemmRow3): the three taps of a filter row read
+// the SAME input rows shifted by one pixel, so ONE staged A tile of BM + 2 consecutive (flattened) pixels serves
+// all three -- tap t of output pixel i reads LDS row i + t.  The implicit-GEMM kernels above are bound by the
+// L2 -> LDS operand traffic (profiles/r1_notes.md); this cuts the activation side of it 3x (9 -> 3 tile loads per
+// pixel and channel tile).  A lane whose shifted pixel falls off its image row (ox + dx outside [0, IW)) gets a
+// zero fragment: that is the convolution's padding, and it also kills the wrap into the neighbouring row / image.
+// Needs: taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (same x0 for all groups), SX == 1, the output
+// grid as wide as the gathered image, Cred % BK == 0, operands addressable with 32 bits.
+// One LDS stage (the next stage waits in registers): 41 KB for 128x128x64B, three workgroups per CU.
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB>
+__global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams p) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BK = BKB / (int)sizeof(T);
+  constexpr int CPR = BKB / 16;
+  constexpr int LDR = BKB + 16;
+  constexpr int AR = BM + 2;                              // staged pixel rows
+  constexpr int A_IT = (AR * CPR + 255) / 256;
+  constexpr int B_IT = BN * CPR / 256;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(B_IT >= 1 && MI >= 1 && NI >= 1 && 256 % CPR == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sa = smem;
+  unsigned char* sb = smem + AR * LDR;                    // [3][BN] rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const uint32_t tiles_n = (p.N + BN - 1) / BN;
+  const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / tiles_n, nt = lid - mt * tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)blockIdx.y * p.b_gstride * sizeof(T);
+
+  const int x0 = __builtin_amdgcn_readfirstlane(p.taps[1]);        // dx of the first tap of every group
+  const int ngroups = p.ntaps / 3;
+  const int kpt = p.Cred / BK;
+
+  // ---- staged rows of this thread: flattened pixel q = m0 + row + x0, fixed for the whole kernel ------------
+  const int ch = tid % CPR;
+  int oys[A_IT], pixb[A_IT];         // oy * SY, and pixel index of (n, 0, ox) in the gathered image; < 0: no such pixel
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int row = (tid + i * 256) / CPR;
+    const long q = (long)m0 + row + x0;
+    if (row < AR && q >= 0 && q < (long)p.M) {
+      const uint32_t n = fdiv((uint32_t)q, p.div_ohow);
+      const uint32_t rem = (uint32_t)q - n * p.div_ohow.d;
+      const uint32_t oy = fdiv(rem, p.div_ow);
+      const uint32_t ox = rem - oy * p.div_ow.d;
+      oys[i] = (int)oy * p.SY;
+      pixb[i] = (int)(n * p.IH * p.IW + ox);
+    } else {
+      oys[i] = 0;
+      pixb[i] = -1;
+    }
+  }
+  uint32_t boff[B_IT], bmask[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = n0 + (tid + i * 256) / CPR;
+    const bool ok = n < p.N;
+    boff[i] = (uint32_t)(((size_t)(ok ? n : 0) * p.ldb + ch * VEC) * sizeof(T));
+    bmask[i] = ok ? 0xffffffffu : 0u;
+  }
+  // ---- per-lane padding masks of the fragment rows this lane feeds to the MFMAs ------------------------------
+  uint32_t fmask[MI][3];
+#pragma unroll
+  for (int b = 0; b < MI; ++b) {
+    const uint32_t m = (uint32_t)(m0 + wm * WTM + b * 32 + l31);
+    int ox = 0;
+    if (m < (uint32_t)p.M) {
+      const uint32_t n = fdiv(m, p.div_ohow);
+      const uint32_t rem = m - n * p.div_ohow.d;
+      ox = (int)(rem - fdiv(rem, p.div_ow) * p.div_ow.d);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      fmask[b][t] = ((unsigned)(ox + x0 + t) < (unsigned)p.IW) ? 0xffffffffu : 0u;
+  }
+
+  uint4 ra[A_IT], rb[3][B_IT];
+  uint32_t aoff[A_IT], amask[A_IT];
+  size_t kb_tap[3] = {0, 0, 0};
+  int lt_g = 0, lt_kc = 0;
+  auto set_group = [&](int g) {
+    const int dy = __builtin_amdgcn_readfirstlane(p.taps[9 * g]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      kb_tap[t] = (size_t)__builtin_amdgcn_readfirstlane(p.taps[9 * g + 3 * t + 2]) * p.Cred;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = oys[i] + dy;
+      const bool ok = pixb[i] >= 0 && (unsigned)iy < (unsigned)p.IH;
+      aoff[i] = ok ? ((uint32_t)(pixb[i] + iy * p.IW) * (uint32_t)p.lda + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T) : 0u;
+      amask[i] = ok ? 0xffffffffu : 0u;
+    }
+  };
+  auto load_stage = [&]() {
+    if (lt_kc == 0) set_group(lt_g);
+    const int c0 = lt_kc * BK;
+    const char* Ak = Ag + (size_t)c0 * sizeof(T);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + aoff[i]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const char* Bk = Bg + (kb_tap[t] + c0) * sizeof(T);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) rb[t][i] = *reinterpret_cast<const uint4*>(Bk + boff[i]);
+    }
+    if (++lt_kc == kpt) {
+      lt_kc = 0;
+      ++lt_g;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = (tid + i * 256) / CPR;
+      if (row < AR) {
+        uint4 v = ra[i];
+        v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
+        *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int row = (tid + i * 256) / CPR;
+        uint4 v = rb[t][i];
+        v.x &= bmask[i]; v.y &= bmask[i]; v.z &= bmask[i]; v.w &= bmask[i];
+        *reinterpret_cast<uint4*>(sb + (t * BN + row) * LDR + ch * 16) = v;
+      }
+  };
+
+  f32x16_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nstages = ngroups * kpt;
+  load_stage();
+  store_stage();
+  __syncthreads();
+  for (int st = 0; st < nstages; ++st) {
+    if (st + 1 < nstages) load_stage();                   // in flight while this stage is consumed
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < BKB / 32; ++ks) {
+        uint4 wf[NI], xf[MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+          wf[a] = *reinterpret_cast<const uint4*>(sb + (t * BN + wn * WTN + a * 32 + l31) * LDR + ks * 32 + lh * 16);
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+          uint4 v = *reinterpret_cast<const uint4*>(sa + (wm * WTM + b * 32 + l31 + t) * LDR + ks * 32 + lh * 16);
+          const uint32_t k = fmask[b][t];
+          v.x &= k; v.y &= k; v.z &= k; v.w &= k;
+          xf[b] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < MI; ++b) Mma<T>::run(acc[a][b], wf[a], xf[b]);
+      }
+    }
+    __syncthreads();                                      // every wave is done reading this stage
+    if (st + 1 < nstages) {
+      store_stage();
+      __syncthreads();
+    }
+  }
+
+  igemm_epilogue<TOut, BM, BN, false>(p, acc, smem, m0, n0, mt);
+}
+
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB>
+void launch_row3(const IgemmParams& p, hipStream_t stream) {
+  constexpr int LDR = BKB + 16;
+  constexpr int stage_bytes = (BM + 2 + 3 * BN) * LDR;
+  constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
+  constexpr int red_bytes = 4 * 2 * BN * 4;
+  constexpr int lds = stage_bytes > epi_bytes ? (stage_bytes > red_bytes ? stage_bytes : red_bytes)
+                                              : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
+  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB>;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)p.groups), dim3(256), lds, stream, p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS-DMA main loop: the same tile computation, staged with global_load_lds_dwordx4 into an S-deep ring
 // of unpadded LDS tiles so that S-1 K tiles (not one) are in flight per workgroup while one is consumed --
 // the register-staged loop above is bound by bytes in flight per CU on the memory-bound layers.
@@ -706,6 +911,7 @@ constexpr TileCfg kCfgs[] = {
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int g_force_cfg = -1;
+int g_row3_mode = -1;
 
 // Pure function of the problem: the stats slab allocation (igemm_stats_rows) must agree with the launch.
 // Measured (MI355X, batch 256 ResNet-50 shapes): 64-byte K tiles (40 KB LDS, 3-4 blocks/CU) win whenever
@@ -736,6 +942,21 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
                       (double)p.N * p.ldb * ES < 4294967296.0;
   const bool aligned = p.Cred % (64 / ES) == 0 && fits32;
   const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
+  if constexpr (EXT) {
+    if ((p.flags & kIgemmRow3) && !(p.flags & kIgemmBnBwd) && aligned && g_force_cfg < 0 && g_row3_mode != 0 &&
+        p.ntaps % 3 == 0 && p.SX == 1 && (int)p.div_ow.d == p.IW) {
+      // measured (scratch/row3_check.py, batch 1024): 64-byte K tiles win up to 256 channels, 128-byte from 512
+      const bool k128 = p.Cred % (128 / ES) == 0 && (g_row3_mode == 2 || (g_row3_mode < 0 && p.Cred * ES >= 1024));
+      if (p.N > 64) {
+        if (k128) launch_row3<T, TOut, 128, 128, 128, 2>(p, stream);
+        else launch_row3<T, TOut, 128, 128, 64, 3>(p, stream);
+      } else {
+        if (k128) launch_row3<T, TOut, 128, 64, 128, 3>(p, stream);
+        else launch_row3<T, TOut, 128, 64, 64, 4>(p, stream);
+      }
+      return;
+    }
+  }
   if (!aligned) {
     if (p.flags & kIgemmBnBwd)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs a 16-bit, 64-byte aligned problem");
@@ -825,6 +1046,7 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 }
 
 void igemm_force_config(int cfg) { g_force_cfg = cfg; }
+void igemm_set_row3(int mode) { g_row3_mode = mode; }
 int igemm_num_configs() { return kNumCfgs; }
 
 int igemm_tile_m(int /*dtype*/) { return 128; }

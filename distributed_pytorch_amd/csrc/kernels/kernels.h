@@ -6,7 +6,9 @@
 namespace dpa {
 
 // ------------------------------------------------------------------------------ igemm.hip
-enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4 };
+// kIgemmRow3: the caller guarantees taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (one x0 for all
+// groups): 3x3-like stride-1 "same" convolutions may then run the filter-row kernel (one staged A tile per 3 taps)
+enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -43,6 +45,8 @@ int igemm_tile_m(int dtype);
 int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype);
 // tuning hook: force tile configuration `cfg` (16-bit in == out problems), -1 = automatic
 void igemm_force_config(int cfg);
+// tuning hook for the filter-row kernel: -1 automatic, 0 never, 1 64-byte K tiles, 2 128-byte K tiles
+void igemm_set_row3(int mode);
 int igemm_num_configs();
 
 // ------------------------------------------------------------------------------ wgrad.hip

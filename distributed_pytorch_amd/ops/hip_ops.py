@@ -32,6 +32,7 @@ def C():
     if _C is None:
         _C = backend.require()
         _C.bn_set_reverse(_BN_REVERSE)
+        _C.igemm_set_row3(int(os.environ.get("DPA_IGEMM_ROW3", "-1")))   # filter-row kernel: -1 auto, 0 off
     return _C
 
 
@@ -225,9 +226,11 @@ def _conv_out(i, k, s, p):
 
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
-           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None):
-    """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group."""
-    flags = (C().IGEMM_RELU if relu else 0)
+           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False):
+    """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
+    ``row3``: the tap table is sorted into filter rows (dy, dx ascending, three taps per row): stride-1 "same"
+    convolutions may use the filter-row kernel (one staged activation tile per three taps)."""
+    flags = (C().IGEMM_RELU if relu else 0) | (C().IGEMM_ROW3 if row3 else 0)
     gargs = (1, 0, 0, 0, 0) if groups is None else groups
     bn_x = bn_z = bn_coef = bn_relu = 0
     if bnred is not None:               # (bn input, bn output or None, coef[4][N], relu mode)
@@ -300,7 +303,7 @@ class _ConvFn(torch.autograd.Function):
         if bias is not None:
             bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
         _igemm(x, wc, y, bias_f, stats, taps, M, K, Cx, R * S, Cx, R * S * Cx, K, IH, IW, sh, sw, OH, OW,
-               relu=relu, dtype=x.dtype, out_dtype=x.dtype)
+               relu=relu, dtype=x.dtype, out_dtype=x.dtype, row3=(S == 3 and sw == 1 and pw == 1))
         ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
         # x is the output of a training-mode BatchNorm: the data-gradient epilogue can produce that BN's
@@ -426,12 +429,15 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None):
         accum = dx                          # covered ones accumulate in place (same thread reads then writes)
     else:
         dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
+    row3 = S == 3 and (sh, sw) == (1, 1) and pw == 1 and OW == IW
     for py, px, taps in classes:
         if not taps:
             continue
         SH, SW = (IH - py + sh - 1) // sh, (IW - px + sw - 1) // sw   # sub-grid extent
         if SH <= 0 or SW <= 0:
             continue
+        if row3:
+            taps = tuple(sorted(taps))          # filter rows: dy, then dx ascending (-1, 0, 1)
         tt = _tap_table(dy.device, taps)
         scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
         slab = None
@@ -441,7 +447,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None):
             slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
         _igemm(dy, wt, dx, None, slab, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
                SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
-               bnred=bnred if slab is not None else None)
+               bnred=bnred if slab is not None else None, row3=row3)
         if slab is not None:
             _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version)
     return dx
