@@ -354,7 +354,12 @@ def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     slab, xptr, _ = hip_ops._pending_bnred.pop(dx.data_ptr())
     assert xptr == bn_x.data_ptr()
     ref_dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum)
-    assert torch.equal(dx, ref_dx)                                                # the gradient itself is untouched
+    # the gradient itself is untouched (3x3: the reference launch takes the filter-row kernel, whose fp32
+    # summation order differs -> equal to bf16 rounding, not bit for bit)
+    if k == 1:
+        assert torch.equal(dx, ref_dx)
+    else:
+        _close(dx, ref_dx, dt, scale=0.5, what="dgrad with fused reduction vs plain")
     M = N * H * H
     nblk = C.bn_partial_rows(M, Cin)
     part = torch.empty(nblk, 2, Cin, device=DEV)
