@@ -278,19 +278,30 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
     }
     __syncthreads();
     if (!is_last) return;
+    // last arriver: fold the chunk sums, again 4 part lanes x 4 independent rows in flight (fixed order)
+    s1 = s2 = 0.0;
+    if (c < C) {
+      int k = pl;
+      for (; k + 12 < a.nchunk; k += 16) {
+        const double a0 = a.tmp[((size_t)k * 2 + 0) * C + c], b0 = a.tmp[((size_t)k * 2 + 1) * C + c];
+        const double a1 = a.tmp[((size_t)(k + 4) * 2 + 0) * C + c], b1 = a.tmp[((size_t)(k + 4) * 2 + 1) * C + c];
+        const double a2 = a.tmp[((size_t)(k + 8) * 2 + 0) * C + c], b2 = a.tmp[((size_t)(k + 8) * 2 + 1) * C + c];
+        const double a3 = a.tmp[((size_t)(k + 12) * 2 + 0) * C + c], b3 = a.tmp[((size_t)(k + 12) * 2 + 1) * C + c];
+        s1 += (a0 + a1) + (a2 + a3);
+        s2 += (b0 + b1) + (b2 + b3);
+      }
+      for (; k < a.nchunk; k += 4) {
+        s1 += a.tmp[((size_t)k * 2 + 0) * C + c];
+        s2 += a.tmp[((size_t)k * 2 + 1) * C + c];
+      }
+    }
+    red[0][pl][cl] = s1;
+    red[1][pl][cl] = s2;
+    __syncthreads();
   }
   if (pl != 0 || c >= C) return;
-  double t1, t2;
-  if (a.nchunk > 1) {
-    t1 = t2 = 0.0;
-    for (int k = 0; k < a.nchunk; ++k) {
-      t1 += a.tmp[((size_t)k * 2 + 0) * C + c];
-      t2 += a.tmp[((size_t)k * 2 + 1) * C + c];
-    }
-  } else {
-    t1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-    t2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-  }
+  const double t1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  const double t2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   if (MODE == 0) {
     if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
     const double m = t1 / a.count;
@@ -653,9 +664,11 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
 
 // Rows of the scratch slab bn_fold_finalize needs for `nparts` partial rows (1 = no scratch pass).
 int bn_fold_chunks(int nparts) {
+  // The fold is latency bound: 64 rows per workgroup = ONE trip of 16 rows per lane with every load in flight.
+  // (Batch-1024 slabs have 25k rows; at 32 chunks a lane walked 196 rows in 12 dependent trips: 27 us per layer.)
   if (nparts <= 64) return 1;
-  int n = (nparts + 31) / 32;          // >= 32 rows per workgroup
-  return n > 32 ? 32 : n;
+  int n = (nparts + 63) / 64;
+  return n > 512 ? 512 : n;
 }
 
 static void fold_finalize_launch(int mode, BnFinalizeArgs a, hipStream_t s) {
