@@ -315,6 +315,8 @@ class _ConvFn(torch.autograd.Function):
                     and bnsrc.x.shape == x.shape and bnsrc.x.dtype == x.dtype:
                 ctx.bnsrc = bnsrc
         ctx.save_for_backward(x, weight, y if relu else None)
+        # no zero tensors for the outputs nobody differentiates (the statistics slab is up to 51 MB per layer)
+        ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(stats)
         # skip=True also returns an alias of the input for the residual branch: its gradient comes back into
@@ -324,6 +326,8 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dstats=None, dalias=None):
+        if dy is None:                      # only the alias was used downstream
+            return dalias, None, None, None, None, None, None, None, None, None
         x, weight, y = ctx.saved_tensors
         (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
         NB, IH, IW, Cx = x.shape
@@ -337,8 +341,6 @@ class _ConvFn(torch.autograd.Function):
             C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
             dy = dym
         dx = dw = db = None
-        if dy is None:                      # only the alias was used downstream
-            return dalias, None, None, None, None, None, None, None, None, None
         wgrad_done = False
         _sk = grad_sink.sink_of(weight)
         if ctx.needs_input_grad[1] and _WGRAD_STREAM and dy.is_cuda and (_sk is None or _sk.on_ready is None):
@@ -597,12 +599,15 @@ class _GroupConvFn(torch.autograd.Function):
         ctx.geom = (stride, padding, groups, m, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, dstats=None):
+        if dy is None:
+            return (None,) * 9
         x, weight, y = ctx.saved_tensors
         (sh, sw), (ph, pw), groups, m, relu, needs_input_grad, has_bias = ctx.geom
         NB, IH, IW, Cx = x.shape
@@ -1477,12 +1482,15 @@ class _StemS2DFn(torch.autograd.Function):
         ctx.cfg = (relu, bias is not None)
         ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, dstats=None):
+        if dy is None:
+            return None, None, None, None, None
         x, weight, y = ctx.saved_tensors
         relu, has_bias = ctx.cfg
         NB, H2, W2, _ = x.shape
