@@ -50,6 +50,16 @@ template <typename T> struct Vec16 {
   uint4 raw;
   __device__ __forceinline__ void load(const void* p) { raw = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void store(void* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  // streaming variants (nt): data that is touched once and is far larger than the caches
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  __device__ __forceinline__ void load_nt(const void* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    raw = make_uint4(v.x, v.y, v.z, v.w);
+  }
+  __device__ __forceinline__ void store_nt(void* p) const {
+    u32x4_t v = {raw.x, raw.y, raw.z, raw.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+  }
   __device__ __forceinline__ float get(int i) const {
     T t;
     __builtin_memcpy(&t, reinterpret_cast<const char*>(&raw) + i * sizeof(T), sizeof(T));

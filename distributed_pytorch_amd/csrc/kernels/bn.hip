@@ -47,6 +47,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   // from x (no residual): the output tensor is not read at all.  relu & 4: ReLU6, the mask also needs y < 6.
   const int rm = relu & 3;
   const bool clip = (relu & 4) != 0;
+  const bool ntl = (relu & 256) != 0;          // streaming loads (tuning hook)
   float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -99,9 +100,15 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = (size_t)(r + u * rp) * C + c0;
-        va[u].load(a + off);
-        if (MODE == 1) vx[u].load(x + off);
-        if (MODE == 1 && rm == 1) vy[u].load(y + off);
+        if (ntl) {
+          va[u].load_nt(a + off);
+          if (MODE == 1) vx[u].load_nt(x + off);
+          if (MODE == 1 && rm == 1) vy[u].load_nt(y + off);
+        } else {
+          va[u].load(a + off);
+          if (MODE == 1) vx[u].load(x + off);
+          if (MODE == 1 && rm == 1) vy[u].load(y + off);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accumulate(va[u], vx[u], vy[u]);
@@ -351,6 +358,9 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, f
 
 int g_bn_grid = 256 * 8;     // tuning hooks (bench/bn_layers.py): workgroups of the streaming kernels, unroll
 int g_bn_unroll = 1;
+long g_nt_min_bytes = 32l << 20;    // tensors at least this large are streamed with nontemporal loads / stores
+                                    // (they cannot stay in the 256 MB Infinity Cache anyway): +1.5 % on the bench
+inline bool nt_auto(long bytes) { return g_nt_min_bytes >= 0 && bytes >= g_nt_min_bytes; }
 int g_bn_reverse = 0;        // 1: the apply kernels walk their tensors from the END (what the producer wrote last
                              // is still in the Infinity Cache / L2)
 
@@ -360,6 +370,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu, int rev) {
   constexpr int VEC = 16 / (int)sizeof(T);
+  const bool nts = (rev & 2) != 0, ntl = (rev & 4) != 0;      // streaming stores / loads (tuning hook)
+  rev &= 1;
   const long stride = (long)gridDim.x * blockDim.x;
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -375,7 +387,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     for (; i + (U - 1) * stride < nchunks; i += U * stride) {
       Vec16<T> vx[U], vr[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) vx[u].load(x + (i + u * stride) * VEC);
+      for (int u = 0; u < U; ++u) {
+        if (ntl) vx[u].load_nt(x + (i + u * stride) * VEC);
+        else vx[u].load(x + (i + u * stride) * VEC);
+      }
       if (res != nullptr) {
 #pragma unroll
         for (int u = 0; u < U; ++u) vr[u].load(res + (i + u * stride) * VEC);
@@ -391,7 +406,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
           if (relu & 4) v = fminf(v, 6.f);
           vo.set(j, v);
         }
-        vo.store(y + (i + u * stride) * VEC);
+        if (nts) vo.store_nt(y + (i + u * stride) * VEC);
+        else vo.store(y + (i + u * stride) * VEC);
       }
     }
   }
@@ -403,7 +419,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       load_coef<VEC>(shift, c0, shv);
     }
     Vec16<T> vx, vr, vo;
-    vx.load(x + q * VEC);
+    if (ntl) vx.load_nt(x + q * VEC);
+    else vx.load(x + q * VEC);
     if (res != nullptr) vr.load(res + q * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -413,7 +430,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       if (relu & 4) v = fminf(v, 6.f);
       vo.set(j, v);
     }
-    vo.store(y + q * VEC);
+    if (nts) vo.store_nt(y + q * VEC);
+    else vo.store(y + q * VEC);
   }
 }
 
@@ -483,6 +501,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   float ca[VEC], cb[VEC], ck[VEC], sc[VEC], sh[VEC];
+  const bool nts = (rev & 2) != 0, ntl = (rev & 4) != 0;      // streaming stores / loads (tuning hook)
+  rev &= 1;
   const int rm = relu & 3;             // see col_reduce_kernel
   const bool clip = (relu & 4) != 0;
   if (i >= nchunks) return;
@@ -503,8 +523,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       load_coef<VEC>(coef + 4 * C, c0, sh);
     }
     Vec16<T> vd, vx, vy, vo, vr;
-    vd.load(dy + q * VEC);
-    vx.load(x + q * VEC);
+    if (ntl) { vd.load_nt(dy + q * VEC); vx.load_nt(x + q * VEC); }
+    else { vd.load(dy + q * VEC); vx.load(x + q * VEC); }
     if (rm == 1) vy.load(y + q * VEC);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -517,7 +537,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
       vr.set(j, d);
     }
-    vo.store(dx + q * VEC);
+    if (nts) vo.store_nt(dx + q * VEC);
+    else vo.store(dx + q * VEC);
     if (dres != nullptr) vr.store(dres + q * VEC);
   }
 }
@@ -582,7 +603,8 @@ void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, 
                           const float* mean, const float* invstd, int relu, const float* scale,
                           const float* shift, float* partial, int nblk, hipStream_t s) {
   if ((relu & 3) == 2 && (scale == nullptr || shift == nullptr)) throw std::invalid_argument("bn: relu mode 2 needs scale/shift");
-  col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu, scale, shift, partial, nblk, s);
+  const bool nt = (g_bn_reverse & 64) || nt_auto(M * C * (dtype == kF32 ? 4l : 2l));
+  col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu | (nt ? 256 : 0), scale, shift, partial, nblk, s);
 }
 
 void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* count_dev,
@@ -619,15 +641,16 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
   const int grid = grid_for(nchunks);
+  const bool nt = nt_auto(nchunks * 16);
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, g_bn_reverse & 1));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1)));
   } else if (g_bn_unroll >= 2) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, g_bn_reverse & 1));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1)));
   } else {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, g_bn_reverse & 1));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1)));
   }
   DPA_CHECK_HIP(hipGetLastError());
 }
@@ -658,7 +681,7 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
   const int grid = grid_for(nchunks);
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
-                                               coef, relu, (g_bn_reverse >> 1) & 1));
+                                               coef, relu, ((g_bn_reverse >> 1) & 1) | (nt_auto(nchunks * 16) ? 6 : ((g_bn_reverse >> 4) & 3) << 1)));
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -711,6 +734,10 @@ void bn_set_tuning(int grid_blocks, int unroll) {
   g_bn_grid = grid_blocks > 0 ? grid_blocks : 256 * 8;
   g_bn_unroll = unroll > 0 ? unroll : 1;
 }
-void bn_set_reverse(int mask) { g_bn_reverse = mask; }   // bit 0: forward apply, bit 1: backward apply
+// bit 0: forward apply walks from the end, bit 1: backward apply does; bits 2-3: forward apply streaming stores /
+// loads; bits 4-5: backward apply streaming stores / loads; bit 6: backward reduce streaming loads (nontemporal)
+void bn_set_reverse(int mask) { g_bn_reverse = mask; }
+void set_nt_min_bytes(long bytes) { g_nt_min_bytes = bytes; }
+long nt_min_bytes() { return g_nt_min_bytes; }
 
 }  // namespace dpa

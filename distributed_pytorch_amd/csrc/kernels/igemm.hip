@@ -178,7 +178,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       }
     }
     if (ncol + VECO <= p.N) {
-      v.store(dst);
+      if (p.flags & kIgemmNtStore) v.store_nt(dst);
+      else v.store(dst);
     } else {
 #pragma unroll
       for (int j = 0; j < VECO; ++j)
@@ -912,6 +913,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int g_force_cfg = -1;
 int g_row3_mode = -1;
+int g_nt_store = 0;
 
 // Pure function of the problem: the stats slab allocation (igemm_stats_rows) must agree with the launch.
 // Measured (MI355X, batch 256 ResNet-50 shapes): 64-byte K tiles (40 KB LDS, 3-4 blocks/CU) win whenever
@@ -1017,6 +1019,11 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     if (p.flags & kIgemmBnBwd) throw std::invalid_argument("igemm: fused BN-backward reduction is dense only");
   }
   if (p.stats_ld <= 0) p.stats_ld = p.N;
+  {
+    const long mb = nt_min_bytes();
+    if (g_nt_store > 0 || (g_nt_store == 0 && mb >= 0 && (long)p.M * p.N * p.groups * (out_dtype == kF32 ? 4 : 2) >= mb))
+      p.flags |= kIgemmNtStore;
+  }
   if (p.Cred % vec != 0 || p.lda % vec != 0 || p.ldb % vec != 0)
     throw std::invalid_argument("igemm: reduction channels / strides must be multiples of 16 bytes");
   const int veco = out_dtype == kF32 ? 4 : 8;
@@ -1047,6 +1054,7 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 
 void igemm_force_config(int cfg) { g_force_cfg = cfg; }
 void igemm_set_row3(int mode) { g_row3_mode = mode; }
+void igemm_set_nt_store(int mode) { g_nt_store = mode; }   // 0: by size (nt_min_bytes), 1: always, -1: never
 int igemm_num_configs() { return kNumCfgs; }
 
 int igemm_tile_m(int /*dtype*/) { return 128; }

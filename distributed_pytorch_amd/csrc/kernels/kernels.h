@@ -8,7 +8,7 @@ namespace dpa {
 // ------------------------------------------------------------------------------ igemm.hip
 // kIgemmRow3: the caller guarantees taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (one x0 for all
 // groups): 3x3-like stride-1 "same" convolutions may then run the filter-row kernel (one staged A tile per 3 taps)
-enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8 };
+enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -47,6 +47,10 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 void igemm_force_config(int cfg);
 // tuning hook for the filter-row kernel: -1 automatic, 0 never, 1 64-byte K tiles, 2 128-byte K tiles
 void igemm_set_row3(int mode);
+void igemm_set_nt_store(int mode);  // streaming (nontemporal) stores of the output tile: 0 by size, 1 always, -1 never
+// tensors of at least this many bytes are streamed with nontemporal loads / stores (negative: never)
+void set_nt_min_bytes(long bytes);
+long nt_min_bytes();
 int igemm_num_configs();
 
 // ------------------------------------------------------------------------------ wgrad.hip
