@@ -393,7 +393,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       }
       if (res != nullptr) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) vr[u].load(res + (i + u * stride) * VEC);
+        for (int u = 0; u < U; ++u) {
+          if (ntl) vr[u].load_nt(res + (i + u * stride) * VEC);
+          else vr[u].load(res + (i + u * stride) * VEC);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -421,7 +424,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     Vec16<T> vx, vr, vo;
     if (ntl) vx.load_nt(x + q * VEC);
     else vx.load(x + q * VEC);
-    if (res != nullptr) vr.load(res + q * VEC);
+    if (res != nullptr) {
+      if (ntl) vr.load_nt(res + q * VEC);
+      else vr.load(res + q * VEC);
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float v = vx.get(j) * scv[j] + shv[j];
@@ -525,7 +531,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     Vec16<T> vd, vx, vy, vo, vr;
     if (ntl) { vd.load_nt(dy + q * VEC); vx.load_nt(x + q * VEC); }
     else { vd.load(dy + q * VEC); vx.load(x + q * VEC); }
-    if (rm == 1) vy.load(y + q * VEC);
+    if (rm == 1) {
+      if (ntl) vy.load_nt(y + q * VEC);
+      else vy.load(y + q * VEC);
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float d = vd.get(j);
@@ -539,7 +548,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     if (nts) vo.store_nt(dx + q * VEC);
     else vo.store(dx + q * VEC);
-    if (dres != nullptr) vr.store(dres + q * VEC);
+    if (dres != nullptr) {
+      if (nts) vr.store_nt(dres + q * VEC);
+      else vr.store(dres + q * VEC);
+    }
   }
 }
 
