@@ -147,10 +147,11 @@ PYBIND11_MODULE(_C, m) {
                                 ptr<float>(dbeta), ptr<float>(coef), st(s));
   });
   m.def("bn_apply", [](uintptr_t x, uintptr_t res, uintptr_t y, long M, int C, int dtype, uintptr_t scale,
-                       uintptr_t shift, int relu, uintptr_t s) {
+                       uintptr_t shift, int relu, uintptr_t s, uintptr_t mask) {
     bn_apply_launch(ptr<const void>(x), ptr<const void>(res), ptr<void>(y), M, C, dtype, ptr<const float>(scale),
-                    ptr<const float>(shift), relu, st(s));
-  });
+                    ptr<const float>(shift), relu, st(s), ptr<uint8_t>(mask));
+  }, py::arg("x"), py::arg("res"), py::arg("y"), py::arg("M"), py::arg("C"), py::arg("dtype"), py::arg("scale"),
+     py::arg("shift"), py::arg("relu"), py::arg("stream"), py::arg("mask") = 0);
   m.def("bn_bwd_reduce", [](uintptr_t dy, uintptr_t x, uintptr_t y, long M, int C, int dtype, uintptr_t mean,
                             uintptr_t invstd, int relu, uintptr_t scale, uintptr_t shift, uintptr_t partial, int nblk,
                             uintptr_t s) {

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   const int c0 = (cc0 + col) * VEC;
 
   // relu & 3: 0 none, 1 mask = (y > 0) read from the saved output, 2 mask = (scale*x + shift > 0) recomputed
-  // from x (no residual): the output tensor is not read at all.  relu & 4: ReLU6, the mask also needs y < 6.
+  // from x (no residual): the output tensor is not read at all, 3 mask = one BIT per element written by the
+  // forward apply pass (`y` then points at bytes, one per 16-byte chunk): 1/16 of the output's bytes.
+  // relu & 4: ReLU6, the mask also needs y < 6.
   const int rm = relu & 3;
   const bool clip = (relu & 4) != 0;
   const bool ntl = (relu & 256) != 0;          // streaming loads (tuning hook)
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   }
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min(M, r_begin + rows_per_block);
-  auto accumulate = [&](const Vec16<T>& va, const Vec16<T>& vx, const Vec16<T>& vy) {
+  auto accumulate = [&](const Vec16<T>& va, const Vec16<T>& vx, const Vec16<T>& vy, uint32_t bits) {
     if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -82,7 +84,9 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       for (int j = 0; j < VEC; ++j) {
         float d = va.get(j);
         const float xv = vx.get(j);
-        if (rm != 0) {
+        if (rm == 3) {
+          if (!((bits >> j) & 1u)) d = 0.f;
+        } else if (rm != 0) {
           const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
           if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
         }
@@ -97,9 +101,11 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
     // 4 rows per trip, every load issued before the first use (the summation order stays fixed)
     for (; r + 3 * rp < r_end; r += 4 * rp) {
       Vec16<T> va[4], vx[4], vy[4];
+      uint32_t mb[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = (size_t)(r + u * rp) * C + c0;
+        if (MODE == 1 && rm == 3) mb[u] = reinterpret_cast<const uint8_t*>(y)[off / VEC];
         if (ntl) {
           va[u].load_nt(a + off);
           if (MODE == 1) vx[u].load_nt(x + off);
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) accumulate(va[u], vx[u], vy[u]);
+      for (int u = 0; u < 4; ++u) accumulate(va[u], vx[u], vy[u], mb[u]);
     }
     for (; r < r_end; r += rp) {
       const size_t off = (size_t)r * C + c0;
@@ -119,7 +125,8 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       va.load(a + off);
       if (MODE == 1) vx.load(x + off);
       if (MODE == 1 && rm == 1) vy.load(y + off);
-      accumulate(va, vx, vy);
+      const uint32_t mb = (MODE == 1 && rm == 3) ? reinterpret_cast<const uint8_t*>(y)[off / VEC] : 0u;
+      accumulate(va, vx, vy, mb);
     }
   }
 #pragma unroll
@@ -368,7 +375,9 @@ template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, long nchunks, int cc,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int relu, int rev) {
+                                                       const float* __restrict__ shift, int relu, int rev,
+                                                       uint8_t* __restrict__ mask) {
+  // mask (optional): one byte per 16-byte chunk, bit j = (y_j > 0) -- all BatchNorm backward needs of the output
   constexpr int VEC = 16 / (int)sizeof(T);
   const bool nts = (rev & 2) != 0, ntl = (rev & 4) != 0;      // streaming stores / loads (tuning hook)
   rev &= 1;
@@ -411,6 +420,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
         if (nts) vo.store_nt(y + (i + u * stride) * VEC);
         else vo.store(y + (i + u * stride) * VEC);
+        if (mask != nullptr) {
+          uint32_t m = 0;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) m |= (vo.get(j) > 0.f ? 1u : 0u) << j;
+          mask[i + u * stride] = (uint8_t)m;
+        }
       }
     }
   }
@@ -438,6 +453,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
     if (nts) vo.store_nt(y + q * VEC);
     else vo.store(y + q * VEC);
+    if (mask != nullptr) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) m |= (vo.get(j) > 0.f ? 1u : 0u) << j;
+      mask[q] = (uint8_t)m;
+    }
   }
 }
 
@@ -535,11 +556,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       if (ntl) vy.load_nt(y + q * VEC);
       else vy.load(y + q * VEC);
     }
+    const uint32_t mbits = rm == 3 ? reinterpret_cast<const uint8_t*>(y)[q] : 0u;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float d = vd.get(j);
       const float xv = vx.get(j);
-      if (rm != 0) {
+      if (rm == 3) {
+        if (!((mbits >> j) & 1u)) d = 0.f;
+      } else if (rm != 0) {
         const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
         if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
       }
@@ -647,7 +671,7 @@ void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgam
 }
 
 void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
-                     const float* scale, const float* shift, int relu, hipStream_t s) {
+                     const float* scale, const float* shift, int relu, hipStream_t s, uint8_t* mask) {
   check_c(C, dtype);
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
@@ -656,13 +680,13 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const bool nt = nt_auto(nchunks * 16);
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1)));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask));
   } else if (g_bn_unroll >= 2) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1)));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask));
   } else {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1)));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask));
   }
   DPA_CHECK_HIP(hipGetLastError());
 }

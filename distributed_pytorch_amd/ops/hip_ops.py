@@ -766,15 +766,20 @@ class _BNFn(torch.autograd.Function):
             residual = residual.contiguous()
         y = torch.empty_like(x)
         clip = 4 if relu == 6 else 0            # ReLU6: bit 2 of the kernels' activation code
-        C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
-                     coef[3].data_ptr(), (1 if relu else 0) | clip, st)
         # ReLU mask in backward: recomputed from x (scale*x + shift > 0) when there is no residual, so the
-        # output is neither saved by this op nor read again; with a residual it comes from y
+        # output is neither saved by this op nor read again; with a residual the apply pass writes one BIT per
+        # element (1/16 of the output's bytes) and backward reads that instead of the output tensor
         relu_mode = 0 if not relu else (1 if residual is not None else 2)
-        ctx.save_for_backward(x, y if relu_mode == 1 else None, weight, coef, count_dev)
+        mask = None
+        if relu_mode == 1 and not clip and not _FUSE_BN_BWD and _BN_BITMASK:
+            relu_mode = 3
+            mask = torch.empty(x.numel() // _vec(x.dtype), dtype=torch.uint8, device=dev)
+        C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
+                     coef[3].data_ptr(), (1 if relu else 0) | clip, st, _p(mask))
+        ctx.save_for_backward(x, mask if relu_mode == 3 else (y if relu_mode == 1 else None), weight, coef, count_dev)
         ctx.bias_ref = bias
         ctx.cfg = (relu_mode | clip, residual is not None, group, count)
-        _BNFn.last = None if clip else _BnSrc(x, coef, relu_mode)
+        _BNFn.last = None if (clip or relu_mode == 3) else _BnSrc(x, coef, relu_mode)
         return y
 
     @staticmethod
@@ -842,6 +847,7 @@ class _BNFn(torch.autograd.Function):
 
 
 _FUSE_STEM = os.environ.get("DPA_FUSE_STEM", "1") == "1"
+_BN_BITMASK = os.environ.get("DPA_BN_BITMASK", "1") == "1"   # residual BN+ReLU: backward reads a bit mask, not the output
 
 
 def can_fuse_bn_relu_maxpool(x: torch.Tensor) -> bool:
