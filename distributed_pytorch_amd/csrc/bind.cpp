@@ -29,8 +29,9 @@ PYBIND11_MODULE(_C, m) {
            int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
            int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream,
            uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu, int groups, long a_gstride, long b_gstride,
-           long c_gstride, int stats_ld) {
+           long c_gstride, int stats_ld, uintptr_t r_mask) {
           IgemmParams p;
+          p.r_mask = ptr<const uint8_t>(r_mask);
           p.groups = groups; p.a_gstride = a_gstride; p.b_gstride = b_gstride; p.c_gstride = c_gstride;
           p.stats_ld = stats_ld;
           p.bn_x = ptr<const void>(bn_x);
@@ -59,7 +60,7 @@ PYBIND11_MODULE(_C, m) {
         py::arg("OWF"), py::arg("OSY"), py::arg("OSX"), py::arg("OY0"), py::arg("OX0"), py::arg("flags"),
         py::arg("dtype"), py::arg("out_dtype"), py::arg("stream"), py::arg("bn_x") = 0, py::arg("bn_z") = 0,
         py::arg("bn_coef") = 0, py::arg("bn_relu") = 0, py::arg("groups") = 1, py::arg("a_gstride") = 0,
-        py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0);
+        py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0, py::arg("r_mask") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
   m.attr("IGEMM_ROW3") = (int)kIgemmRow3;
   m.def("igemm_set_row3", &igemm_set_row3);

@@ -162,15 +162,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     char* dst = Cg + goff;
     if (p.R != nullptr) {      // fused accumulate (gradient of a tensor with two consumers): one rounding
       const char* rsrc = reinterpret_cast<const char*>(p.R) + gofs * sizeof(TOut) + goff;
+      // masked accumulate: R is a gradient that still has to pass a ReLU (its mask bits live next to it)
+      const uint32_t rbits = p.r_mask != nullptr ? p.r_mask[(gofs * sizeof(TOut) + goff) / 16] : 0xffu;
       if (ncol + VECO <= p.N) {
         Vec16<TOut> r;
         r.load(rsrc);
 #pragma unroll
-        for (int j = 0; j < VECO; ++j) v.set(j, v.get(j) + r.get(j));
+        for (int j = 0; j < VECO; ++j) v.set(j, v.get(j) + (((rbits >> j) & 1u) ? r.get(j) : 0.f));
       } else {
 #pragma unroll
         for (int j = 0; j < VECO; ++j) {   // constant j: keeps v in registers (a runtime index sends it to scratch)
-          if (ncol + j < p.N) {
+          if (ncol + j < p.N && ((rbits >> j) & 1u)) {
             TOut t = *reinterpret_cast<const TOut*>(rsrc + j * sizeof(TOut));
             v.set(j, v.get(j) + to_float(t));
           }

@@ -15,6 +15,8 @@ struct IgemmParams {
   const void* B;       // weights [N][ldb], reduction axis contiguous
   void* C;             // output rows of ldc elements
   const void* R;       // optional tensor added in the epilogue (same dtype / rows as C): C = conv + R
+  const uint8_t* r_mask = nullptr;   // optional: one byte per 16-byte chunk of R, bit j = keep element j (the ReLU
+                                     // mask of the BN that produced R's gradient: R is added as R * mask)
   const float* bias;   // optional [N]
   float* stats;        // optional per-channel partial (sum, sum^2) slab [tiles_m][2][N]
   // kIgemmBnBwd (data-gradient launches): the output is the gradient dz of z = [relu](bn(bn_x) [+ res]); the

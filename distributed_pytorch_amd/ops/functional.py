@@ -50,6 +50,9 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     (feeds the fused BatchNorm).  ``needs_input_grad=False`` skips dgrad (stem).
     ``skip=True`` returns ``(result, x_alias)``: feed ``x_alias`` to the residual branch and its
     gradient is added inside this convolution's dgrad epilogue instead of a separate accumulate pass.
+    Contract: use ``x_alias`` ONCE -- as the ``residual`` of the block's last BatchNorm, or as the input of the
+    block's downsample branch.  (A residual BN + ReLU returns the alias's gradient unmasked together with its ReLU
+    bit mask, which only this convolution's epilogue knows how to apply.)
     ``groups > 1``: grouped / depthwise convolution, every pass one launch with the group on ``grid.y``.
     """
     stride, padding = _pair(stride), _pair(padding)

@@ -75,6 +75,7 @@ def bump_generation() -> None:
     global _generation
     _generation += 1
     _pending_bnred.clear()          # never carry a fused BN-backward slab across optimizer steps
+    _pending_mask.clear()
 
 
 class _WCache:
@@ -229,7 +230,8 @@ def _conv_out(i, k, s, p):
 
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
-           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False):
+           scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False,
+           accum_mask=None):
     """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
     ``row3``: the tap table is sorted into filter rows (dy, dx ascending, three taps per row): stride-1 "same"
     convolutions may use the filter-row kernel (one staged activation tile per three taps)."""
@@ -245,7 +247,7 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
         OHF, OWF, OSY, OSX, OY0, OX0 = scatter
     C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
-              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs)
+              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs, _p(accum_mask))
 
 
 def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
@@ -329,7 +331,15 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dstats=None, dalias=None):
+        amask = None
+        if dalias is not None:              # gradient of the residual branch, possibly still carrying its ReLU mask
+            ent = _pending_mask.pop(dalias.data_ptr(), None)
+            if ent is not None and ent[1] == dalias._version and ent[2] == _generation \
+                    and ent[0].numel() * _vec(dalias.dtype) == dalias.numel():
+                amask = ent[0]
         if dy is None:                      # only the alias was used downstream
+            if amask is not None:
+                dalias = apply_bit_mask(dalias, amask)
             return dalias, None, None, None, None, None, None, None, None, None
         x, weight, y = ctx.saved_tensors
         (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
@@ -363,9 +373,10 @@ class _ConvFn(torch.autograd.Function):
             if ctx.bnsrc is not None and ctx.bnsrc.uses == 1:      # sole consumer of that BN's output
                 src = ctx.bnsrc
                 bnred = (src.x, x if src.mode == 1 else None, src.coef, src.mode)
-            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred)
+            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
+                            accum_mask=amask)
         elif dalias is not None:
-            dx = dalias
+            dx = apply_bit_mask(dalias, amask) if amask is not None else dalias
         if ctx.needs_input_grad[1] and not wgrad_done:
             dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
         if has_bias and ctx.needs_input_grad[2]:
@@ -402,6 +413,11 @@ _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "0") == "1"
 # tensor, unmodified: autograd sums gradients of a multiply-used tensor either out of place (new data_ptr)
 # or in place (version bump), and both must fall back to the full reduction.
 _pending_bnred: Dict[int, tuple] = {}
+# data_ptr of a gradient handed to a residual branch WITHOUT its ReLU mask applied -> (bit mask, version, generation).
+# Only produced for residuals tagged `_dpa_alias` (whose sole consumer is _ConvFn.backward, which applies the mask
+# inside the data-gradient epilogue): saves writing the masked copy (one activation-sized tensor per block).
+_pending_mask: Dict[int, tuple] = {}
+_LAZY_DRES = os.environ.get("DPA_LAZY_DRES", "1") == "1"
 
 
 bn_bwd_counts = {"fused": 0, "reduced": 0}      # how BatchNorm backward obtained its partial sums (tests, tuning)
@@ -416,7 +432,14 @@ class _BnSrc:
         self.x, self.coef, self.mode, self.uses = x, coef, mode, 0
 
 
-def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None):
+def apply_bit_mask(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """t * mask for a bit mask written by the BN apply pass (one byte per 16-byte chunk) -- cold paths only."""
+    vec = _vec(t.dtype)
+    bits = (mask.view(-1, 1) >> torch.arange(vec, device=t.device, dtype=torch.uint8)) & 1
+    return (t.contiguous().view(-1, vec) * bits.to(t.dtype)).view(t.shape)
+
+
+def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accum_mask=None):
     NB, IH, IW, Cx = xshape
     K, Cw, R, S = weight.shape
     sh, sw = stride
@@ -429,6 +452,9 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None):
     need_zero = any(len(t) == 0 for _, _, t in classes)
     if accum is not None:
         accum = accum if accum.is_contiguous() else accum.contiguous()
+    if accum_mask is not None and (need_zero or accum is None):
+        accum = apply_bit_mask(accum, accum_mask) if accum is not None else None
+        accum_mask = None
     if need_zero and accum is not None:
         dx = accum.clone()                  # uncovered positions keep the other branch's gradient
         accum = dx                          # covered ones accumulate in place (same thread reads then writes)
@@ -452,7 +478,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None):
             slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
         _igemm(dy, wt, dx, None, slab, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
                SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
-               bnred=bnred if slab is not None else None, row3=row3)
+               bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask)
         if slab is not None:
             _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version)
     return dx
@@ -506,6 +532,10 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
     grad_sink.note_use(weight, bias)
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
                                     bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None))
+    if alias is not None:
+        # its gradient returns to _ConvFn.backward (and nowhere else): a BatchNorm that takes it as the residual may
+        # hand back the UNMASKED gradient plus its ReLU bit mask instead of writing a masked copy
+        alias._dpa_alias = True
     out = (y, stats) if want_stats else y
     return (out, alias) if skip else out
 
@@ -778,6 +808,10 @@ class _BNFn(torch.autograd.Function):
                      coef[3].data_ptr(), (1 if relu else 0) | clip, st, _p(mask))
         ctx.save_for_backward(x, mask if relu_mode == 3 else (y if relu_mode == 1 else None), weight, coef, count_dev)
         ctx.bias_ref = bias
+        # residual = the block input handed out by the first convolution (`skip`): its gradient goes back to that
+        # convolution only, so backward may return dy itself + the bit mask instead of a masked copy
+        ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and getattr(residual, "_dpa_alias", False)
+                            and residual.shape == x.shape and residual.dtype == x.dtype)
         ctx.cfg = (relu_mode | clip, residual is not None, group, count)
         _BNFn.last = None if (clip or relu_mode == 3) else _BnSrc(x, coef, relu_mode)
         return y
@@ -833,9 +867,13 @@ class _BNFn(torch.autograd.Function):
                               g32.data_ptr(), count, _p(count_dev), Cc, wk.data_ptr(), coef[2].data_ptr(),
                               coef[3].data_ptr(), st)
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
+        lazy = has_res and ctx.lazy_res and ctx.needs_input_grad[3]
+        dres = torch.empty_like(x) if (has_res and not lazy) else None
         C().bn_bwd_apply(dy.data_ptr(), x.data_ptr(), _p(y), dx.data_ptr(), _p(dres), M, Cc, _dt(x),
                          wk.data_ptr(), relu, st)
+        if lazy:                 # y is the bit mask here (relu mode 3); the consumer applies it in its dgrad epilogue
+            _pending_mask[dy.data_ptr()] = (y, dy._version, _generation)
+            dres = dy
         if direct:
             sw_.delivered()
             sb_.delivered()

@@ -180,3 +180,42 @@ def test_hip_graph_step_matches_eager_training():
     assert l0 == pytest.approx(l1, rel=1e-5, abs=1e-6), (l0, l1)
     for a, b in zip(p0, p1):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_lazy_residual_gradient_equals_materialised(arch):
+    """Residual BN + ReLU backward hands the UNMASKED gradient + its ReLU bit mask to the block's first convolution,
+    whose data-gradient epilogue applies the mask (no masked copy is written).  Same gradients as the path that
+    writes the masked copy, and the path is really taken."""
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.ops import hip_ops
+
+    amp.state().reset()
+    torch.manual_seed(1)
+    base = models.create_model(arch, num_classes=100).cuda()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    t = torch.randint(0, 100, (4,), device="cuda")
+    res = []
+    try:
+        for lazy in (True, False):
+            hip_ops._LAZY_DRES = lazy
+            seen = []
+            orig = hip_ops._igemm
+
+            def spy(*a, **k):
+                seen.append(k.get("accum_mask") is not None)
+                return orig(*a, **k)
+
+            hip_ops._igemm = spy
+            try:
+                res.append(_run(copy.deepcopy(base), x, t))
+            finally:
+                hip_ops._igemm = orig
+            assert any(seen) == lazy
+            assert not hip_ops._pending_mask          # every mask was consumed by its convolution
+    finally:
+        hip_ops._LAZY_DRES = True
+    (o1, l1, g1), (o2, l2, g2) = res
+    assert torch.equal(o1, o2) and l1 == l2
+    for n in g1:
+        assert torch.allclose(g1[n], g2[n], rtol=1e-5, atol=1e-7), n
