@@ -810,8 +810,10 @@ class _BNFn(torch.autograd.Function):
         ctx.bias_ref = bias
         # residual = the block input handed out by the first convolution (`skip`): its gradient goes back to that
         # convolution only, so backward may return dy itself + the bit mask instead of a masked copy
-        ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and getattr(residual, "_dpa_alias", False)
-                            and residual.shape == x.shape and residual.dtype == x.dtype)
+        # ... or the output of an activation-free BatchNorm (the downsample branch), whose backward takes the bit
+        # mask as its own "ReLU" mask
+        ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and residual.shape == x.shape and residual.dtype == x.dtype
+                            and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)))
         ctx.cfg = (relu_mode | clip, residual is not None, group, count)
         _BNFn.last = None if (clip or relu_mode == 3) else _BnSrc(x, coef, relu_mode)
         return y
@@ -820,6 +822,14 @@ class _BNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, weight, coef, count_dev = ctx.saved_tensors
         relu, has_res, group, count = ctx.cfg
+        ent = _pending_mask.pop(dy.data_ptr(), None)
+        if ent is not None and ent[1] == dy._version and ent[2] == _generation \
+                and ent[0].numel() * _vec(dy.dtype) == dy.numel():
+            # dy is the unmasked gradient of a residual branch: its ReLU bit mask plays the role of this BN's own mask
+            if relu == 0 and dy.is_contiguous():
+                relu, y = 3, ent[0]
+            else:
+                dy = apply_bit_mask(dy, ent[0])
         dy = dy if dy.is_contiguous() else dy.contiguous()
         Cc = x.shape[-1]
         M = x.numel() // Cc
@@ -1040,6 +1050,8 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
         if _BNFn.last is not None and torch.is_grad_enabled():
             y._dpa_bn = _BNFn.last      # lets the consuming convolution fuse this BN's backward reduction
             _BNFn.last = None
+        if not relu and residual is None:
+            y._dpa_bn_plain = True      # activation-free BN output: as a residual its gradient may arrive unmasked + bit mask
         return y
     return _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), _act_code(relu))
 
