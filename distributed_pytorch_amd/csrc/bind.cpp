@@ -148,11 +148,14 @@ PYBIND11_MODULE(_C, m) {
                                 ptr<float>(dbeta), ptr<float>(coef), st(s));
   });
   m.def("bn_apply", [](uintptr_t x, uintptr_t res, uintptr_t y, long M, int C, int dtype, uintptr_t scale,
-                       uintptr_t shift, int relu, uintptr_t s, uintptr_t mask) {
+                       uintptr_t shift, int relu, uintptr_t s, uintptr_t mask, uintptr_t res_scale,
+                       uintptr_t res_shift) {
     bn_apply_launch(ptr<const void>(x), ptr<const void>(res), ptr<void>(y), M, C, dtype, ptr<const float>(scale),
-                    ptr<const float>(shift), relu, st(s), ptr<uint8_t>(mask));
+                    ptr<const float>(shift), relu, st(s), ptr<uint8_t>(mask), ptr<const float>(res_scale),
+                    ptr<const float>(res_shift));
   }, py::arg("x"), py::arg("res"), py::arg("y"), py::arg("M"), py::arg("C"), py::arg("dtype"), py::arg("scale"),
-     py::arg("shift"), py::arg("relu"), py::arg("stream"), py::arg("mask") = 0);
+     py::arg("shift"), py::arg("relu"), py::arg("stream"), py::arg("mask") = 0, py::arg("res_scale") = 0,
+     py::arg("res_shift") = 0);
   m.def("bn_bwd_reduce", [](uintptr_t dy, uintptr_t x, uintptr_t y, long M, int C, int dtype, uintptr_t mean,
                             uintptr_t invstd, int relu, uintptr_t scale, uintptr_t shift, uintptr_t partial, int nblk,
                             uintptr_t s) {

@@ -376,21 +376,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        T* __restrict__ y, long nchunks, int cc,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int relu, int rev,
-                                                       uint8_t* __restrict__ mask) {
+                                                       uint8_t* __restrict__ mask,
+                                                       const float* __restrict__ res_scale,
+                                                       const float* __restrict__ res_shift) {
   // mask (optional): one byte per 16-byte chunk, bit j = (y_j > 0) -- all BatchNorm backward needs of the output
+  // res_scale / res_shift (optional): the residual is the RAW output of another convolution whose (activation-free)
+  // BatchNorm is applied here on the fly: y = act(scale*x + shift + res_scale*res + res_shift)
   constexpr int VEC = 16 / (int)sizeof(T);
   const bool nts = (rev & 2) != 0, ntl = (rev & 4) != 0;      // streaming stores / loads (tuning hook)
   rev &= 1;
   const long stride = (long)gridDim.x * blockDim.x;
   const bool fixed = (stride % cc) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  float scv[VEC], shv[VEC];
+  float scv[VEC], shv[VEC], rsc[VEC], rsh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { rsc[j] = 1.f; rsh[j] = 0.f; }
   // rev: chunk q = nchunks-1-i, i.e. the tensor is walked from its end (the rows the producing kernel wrote
   // last are the ones still cached); q % cc is again constant per thread when the stride is a multiple of cc
   int c0 = (int)((rev ? nchunks - 1 - i : i) % cc) * VEC;
   if (i >= nchunks) return;
   load_coef<VEC>(scale, c0, scv);
   load_coef<VEC>(shift, c0, shv);
+  if (res_scale != nullptr) {
+    load_coef<VEC>(res_scale, c0, rsc);
+    load_coef<VEC>(res_shift, c0, rsh);
+  }
   if (U > 1 && fixed && !rev) {
     // U chunks per thread per trip, all loads issued before the first use: more bytes in flight per wave
     for (; i + (U - 1) * stride < nchunks; i += U * stride) {
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float v = vx[u].get(j) * scv[j] + shv[j];
-          if (res != nullptr) v += vr[u].get(j);
+          if (res != nullptr) v += vr[u].get(j) * rsc[j] + rsh[j];
           if (relu) v = fmaxf(v, 0.f);
           if (relu & 4) v = fminf(v, 6.f);
           vo.set(j, v);
@@ -435,6 +445,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       c0 = (int)(q % cc) * VEC;
       load_coef<VEC>(scale, c0, scv);
       load_coef<VEC>(shift, c0, shv);
+      if (res_scale != nullptr) {
+        load_coef<VEC>(res_scale, c0, rsc);
+        load_coef<VEC>(res_shift, c0, rsh);
+      }
     }
     Vec16<T> vx, vr, vo;
     if (ntl) vx.load_nt(x + q * VEC);
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float v = vx.get(j) * scv[j] + shv[j];
-      if (res != nullptr) v += vr.get(j);
+      if (res != nullptr) v += vr.get(j) * rsc[j] + rsh[j];
       if (relu) v = fmaxf(v, 0.f);
       if (relu & 4) v = fminf(v, 6.f);
       vo.set(j, v);
@@ -671,7 +685,10 @@ void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgam
 }
 
 void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
-                     const float* scale, const float* shift, int relu, hipStream_t s, uint8_t* mask) {
+                     const float* scale, const float* shift, int relu, hipStream_t s, uint8_t* mask,
+                     const float* res_scale, const float* res_shift) {
+  if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale != nullptr && residual == nullptr))
+    throw std::invalid_argument("bn_apply: res_scale / res_shift come in pairs and need a residual");
   check_c(C, dtype);
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
@@ -680,13 +697,13 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const bool nt = nt_auto(nchunks * 16);
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask, res_scale, res_shift));
   } else if (g_bn_unroll >= 2) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask, res_scale, res_shift));
   } else {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(256), 0, s, (const T*)x,
-                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask));
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask, res_scale, res_shift));
   }
   DPA_CHECK_HIP(hipGetLastError());
 }

@@ -108,7 +108,8 @@ void bn_bwd_fold_finalize_launch(const float* partial, int nparts, int C, double
 void bn_set_tuning(int grid_blocks, int unroll);
 void bn_set_reverse(int mask);   // bit 0 / 1: forward / backward apply kernels walk their tensors from the end   // tuning hook for the streaming kernels
 void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C, int dtype,
-                     const float* scale, const float* shift, int relu, hipStream_t s, uint8_t* mask = nullptr);
+                     const float* scale, const float* shift, int relu, hipStream_t s, uint8_t* mask = nullptr,
+                     const float* res_scale = nullptr, const float* res_shift = nullptr);
 // backward: dy masked by (y > 0) when relu; partial [nblk][2][C] = (sum dy, sum dy*xhat).  relu & 3 == 3: `y` is the
 // bit mask bn_apply_launch wrote (one byte per 16-byte chunk), not the output tensor
 void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, int C, int dtype,

@@ -62,8 +62,9 @@ class _ConvBN(nn.Sequential):
         super().__init__(*layers)
         self.act = act
 
-    def forward(self, x, residual=None, relu=None):
-        return conv_bn_act(x, self[0], self[1], relu=self.act if relu is None else relu, residual=residual)
+    def forward(self, x, residual=None, relu=None, defer=False):
+        return conv_bn_act(x, self[0], self[1], relu=self.act if relu is None else relu, residual=residual,
+                           defer=defer)
 
 
 class BottleneckTransform(nn.Sequential):
@@ -86,7 +87,7 @@ class ResBottleneckBlock(nn.Module):
         self.activation = ReLU(inplace=True)
 
     def forward(self, x):
-        identity = self.proj(x) if self.proj is not None else x
+        identity = self.proj(x, defer=True) if self.proj is not None else x      # applied inside f.c's BN pass
         h = self.f.b(self.f.a(x))
         return self.f.c(h, residual=identity, relu=True)          # BN + identity + ReLU in one pass
 

@@ -53,7 +53,7 @@ class BasicBlock(nn.Module):
         # `identity` aliases x: its gradient is added inside conv1's dgrad epilogue
         out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True)
         if self.downsample is not None:
-            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False)
+            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer=True)
         return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity)
 
 
@@ -78,7 +78,7 @@ class Bottleneck(nn.Module):
         out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         if self.downsample is not None:
-            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False)
+            identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)
 
 

@@ -70,10 +70,10 @@ class BatchNorm2d(nn.Module):
         self.process_group = None  # set by convert_syncbn_model
 
     def forward(self, x: torch.Tensor, relu: bool = False, residual: Optional[torch.Tensor] = None,
-                stats=None) -> torch.Tensor:
+                stats=None, defer: bool = False) -> torch.Tensor:
         return F.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var,
                             self.num_batches_tracked, self.training, self.momentum, self.eps,
-                            relu=relu, residual=residual, stats=stats, group=self.process_group)
+                            relu=relu, residual=residual, stats=stats, group=self.process_group, defer=defer)
 
     def extra_repr(self) -> str:
         return "{}, eps={}, momentum={}{}".format(self.num_features, self.eps, self.momentum,
@@ -199,8 +199,9 @@ def conv_bn_relu_maxpool(x, conv: Conv2d, bn: BatchNorm2d, pool: "MaxPool2d"):
                                 pool.ceil_mode, stats=stats, group=bn.process_group)
 
 
-def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False):
-    """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  On the GPU the conv epilogue emits the
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False, defer: bool = False):
+    """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  ``defer=True`` (downsample branches, ``relu=False``): the
+    result may only be used as the ``residual`` of the block's last ``conv_bn_act`` (see ``F.batch_norm``).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
     re-read for statistics.  ``skip=True`` -> ``(out, x_alias)`` (see ``F.conv2d``)."""
     fuse = F._on_gpu(x) and bn.training and bn.process_group is None
@@ -210,7 +211,7 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip
         out, alias = out
     if fuse:
         y, stats = out
-        res = bn(y, relu=relu, residual=residual, stats=stats)
+        res = bn(y, relu=relu, residual=residual, stats=stats, defer=defer)
     else:
-        res = bn(out, relu=relu, residual=residual)
+        res = bn(out, relu=relu, residual=residual, defer=defer)
     return (res, alias) if skip else res

@@ -104,15 +104,18 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
                running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
                num_batches_tracked: Optional[torch.Tensor], training: bool,
                momentum: float = 0.1, eps: float = 1e-5, *, relu: bool = False,
-               residual: Optional[torch.Tensor] = None, stats=None, group=None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, stats=None, group=None, defer: bool = False) -> torch.Tensor:
     """Fused ``BN [+ residual] [+ ReLU]`` over NHWC (N-K4/K5/K7; SyncBN when
     ``group`` is a process group: N-K6).  Statistics are always fp32.
     ``running_var`` receives the unbiased variance, as in torch / cuDNN.
     ``relu=6`` applies ReLU6 (MobileNet) inside the same pass.
+    ``defer=True`` (activation-free BN of a downsample branch): on the GPU in training mode nothing is written --
+    the result aliases ``x`` and MUST only be used as the ``residual`` of another ``batch_norm``, which applies this
+    BN's scale / shift on the fly (one activation-sized write and read less).  Ignored elsewhere.
     """
     if _on_gpu(x):
         return _hip().batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked,
-                                 training, momentum, eps, relu, residual, stats, group)
+                                 training, momentum, eps, relu, residual, stats, group, defer)
     if group is not None and training:
         from ..parallel.sync_batchnorm import sync_batch_norm_reference
 

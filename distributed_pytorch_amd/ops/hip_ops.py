@@ -757,7 +757,7 @@ def _all_reduce_sum(t: torch.Tensor, group) -> None:
 class _BNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, momentum, eps, relu, stats,
-                group):
+                group, defer=False):
         x = x if x.is_contiguous() else x.contiguous()
         Cc = x.shape[-1]
         M = x.numel() // Cc
@@ -792,7 +792,20 @@ class _BNFn(torch.autograd.Function):
                                  g32.data_ptr(), b32.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
                                  _p(nbt), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
                                  coef[3].data_ptr(), st)
+        if defer and not relu and residual is None and world == 1:
+            # Deferred: nothing is written.  The result is an alias of the raw input carrying this BN's (scale,
+            # shift); the BatchNorm that takes it as `residual` applies them on the fly.  Backward is the normal one.
+            ctx.save_for_backward(x, None, weight, coef, count_dev)
+            ctx.bias_ref = bias
+            ctx.lazy_res = False
+            ctx.cfg = (0, False, group, count)
+            _BNFn.last = None
+            _BNFn.deferred = coef
+            return x.view(x.shape)
+        res_coef = getattr(residual, "_dpa_deferred_coef", None) if residual is not None else None
         if residual is not None and not residual.is_contiguous():
+            if res_coef is not None:
+                raise ValueError("a deferred BatchNorm output must reach its consumer untouched")
             residual = residual.contiguous()
         y = torch.empty_like(x)
         clip = 4 if relu == 6 else 0            # ReLU6: bit 2 of the kernels' activation code
@@ -805,7 +818,10 @@ class _BNFn(torch.autograd.Function):
             relu_mode = 3
             mask = torch.empty(x.numel() // _vec(x.dtype), dtype=torch.uint8, device=dev)
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
-                     coef[3].data_ptr(), (1 if relu else 0) | clip, st, _p(mask))
+                     coef[3].data_ptr(), (1 if relu else 0) | clip, st, _p(mask),
+                     res_coef[2].data_ptr() if res_coef is not None else 0,
+                     res_coef[3].data_ptr() if res_coef is not None else 0)
+        ctx.res_coef = res_coef                 # keeps the deferred BN's coefficients alive until backward is done
         ctx.save_for_backward(x, mask if relu_mode == 3 else (y if relu_mode == 1 else None), weight, coef, count_dev)
         ctx.bias_ref = bias
         # residual = the block input handed out by the first convolution (`skip`): its gradient goes back to that
@@ -891,7 +907,7 @@ class _BNFn(torch.autograd.Function):
         else:
             dgamma = _deliver(weight, dg_t.to(weight.dtype)) if ctx.needs_input_grad[1] else None
             dbeta = _deliver(bias_p, db_t.to(bias_p.dtype)) if ctx.needs_input_grad[2] else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 _FUSE_STEM = os.environ.get("DPA_FUSE_STEM", "1") == "1"
@@ -1039,14 +1055,24 @@ def _act_code(relu) -> int:
     return 6 if (relu is not True and relu == 6) else (1 if relu else 0)
 
 
+_DEFER_BN = os.environ.get("DPA_DEFER_BN", "1") == "1"
+
+
 def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps,
-               relu, residual, stats, group):
+               relu, residual, stats, group, defer=False):
+    if getattr(x, "_dpa_deferred_coef", None) is not None:
+        raise ValueError("a deferred BatchNorm output can only be used as the `residual` of another BatchNorm")
     if training or running_mean is None:
         grad_sink.note_use(weight, bias)
         _BNFn.last = None
+        _BNFn.deferred = None
         y = _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
                         running_var if training else None, num_batches_tracked if training else None,
-                        float(momentum if momentum is not None else 0.1), float(eps), _act_code(relu), stats, group)
+                        float(momentum if momentum is not None else 0.1), float(eps), _act_code(relu), stats, group,
+                        bool(defer and _DEFER_BN and training and torch.is_grad_enabled()))
+        if _BNFn.deferred is not None:
+            y._dpa_deferred_coef = _BNFn.deferred
+            _BNFn.deferred = None
         if _BNFn.last is not None and torch.is_grad_enabled():
             y._dpa_bn = _BNFn.last      # lets the consuming convolution fuse this BN's backward reduction
             _BNFn.last = None
