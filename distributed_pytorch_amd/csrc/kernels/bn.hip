@@ -367,7 +367,10 @@ int g_bn_grid = 256 * 8;     // tuning hooks (bench/bn_layers.py): workgroups of
 int g_bn_unroll = 1;
 long g_nt_min_bytes = 32l << 20;    // tensors at least this large are streamed with nontemporal loads / stores
                                     // (they cannot stay in the 256 MB Infinity Cache anyway): +1.5 % on the bench
-inline bool nt_auto(long bytes) { return g_nt_min_bytes >= 0 && bytes >= g_nt_min_bytes; }
+int g_nt_mask = 15;                 // which kernels stream: 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm stores
+inline bool nt_auto(long bytes, int who) {
+  return (g_nt_mask & who) && g_nt_min_bytes >= 0 && bytes >= g_nt_min_bytes;
+}
 int g_bn_reverse = 0;        // 1: the apply kernels walk their tensors from the END (what the producer wrote last
                              // is still in the Infinity Cache / L2)
 
@@ -653,7 +656,7 @@ void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, 
                           const float* mean, const float* invstd, int relu, const float* scale,
                           const float* shift, float* partial, int nblk, hipStream_t s) {
   if ((relu & 3) == 2 && (scale == nullptr || shift == nullptr)) throw std::invalid_argument("bn: relu mode 2 needs scale/shift");
-  const bool nt = (g_bn_reverse & 64) || nt_auto(M * C * (dtype == kF32 ? 4l : 2l));
+  const bool nt = (g_bn_reverse & 64) || nt_auto(M * C * (dtype == kF32 ? 4l : 2l), 4);
   col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu | (nt ? 256 : 0), scale, shift, partial, nblk, s);
 }
 
@@ -694,7 +697,7 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
   const int grid = grid_for(nchunks);
-  const bool nt = nt_auto(nchunks * 16);
+  const bool nt = nt_auto(nchunks * 16, 1);
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
                                                  (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask, res_scale, res_shift));
@@ -734,7 +737,7 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
   const int grid = grid_for(nchunks);
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
-                                               coef, relu, ((g_bn_reverse >> 1) & 1) | (nt_auto(nchunks * 16) ? 6 : ((g_bn_reverse >> 4) & 3) << 1)));
+                                               coef, relu, ((g_bn_reverse >> 1) & 1) | (nt_auto(nchunks * 16, 2) ? 6 : ((g_bn_reverse >> 4) & 3) << 1)));
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -791,6 +794,7 @@ void bn_set_tuning(int grid_blocks, int unroll) {
 // loads; bits 4-5: backward apply streaming stores / loads; bit 6: backward reduce streaming loads (nontemporal)
 void bn_set_reverse(int mask) { g_bn_reverse = mask; }
 void set_nt_min_bytes(long bytes) { g_nt_min_bytes = bytes; }
-long nt_min_bytes() { return g_nt_min_bytes; }
+long nt_min_bytes() { return (g_nt_mask & 8) ? g_nt_min_bytes : -1; }
+void set_nt_mask(int mask) { g_nt_mask = mask; }
 
 }  // namespace dpa

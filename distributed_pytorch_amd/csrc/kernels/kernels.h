@@ -53,6 +53,7 @@ void igemm_set_nt_store(int mode);  // streaming (nontemporal) stores of the out
 // tensors of at least this many bytes are streamed with nontemporal loads / stores (negative: never)
 void set_nt_min_bytes(long bytes);
 long nt_min_bytes();
+void set_nt_mask(int mask);   // 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm output stores
 int igemm_num_configs();
 
 // ------------------------------------------------------------------------------ wgrad.hip

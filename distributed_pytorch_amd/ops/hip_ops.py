@@ -34,6 +34,8 @@ def C():
         _C.bn_set_reverse(_BN_REVERSE)
         _C.igemm_set_row3(int(os.environ.get("DPA_IGEMM_ROW3", "-1")))   # filter-row kernel: -1 auto, 0 off
         _C.igemm_set_nt_store(int(os.environ.get("DPA_IGEMM_NT", "0")))  # 0: by size, 1: always, -1: never
+        if "DPA_NT_MASK" in os.environ:          # 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm stores
+            _C.set_nt_mask(int(os.environ["DPA_NT_MASK"]))
         if "DPA_NT_MIN_MB" in os.environ:        # streaming threshold (default 32 MB); negative: never
             _C.set_nt_min_bytes(int(float(os.environ["DPA_NT_MIN_MB"]) * (1 << 20)))
     return _C
