@@ -125,6 +125,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   // the accumulators are dead by now, so the 2 x E_IT vectors cost no occupancy)
   float bmu[VECO], bis[VECO], bsc[VECO], bsh[VECO];
   uint4 px[E_IT], pz[E_IT];
+  uint32_t pbits[E_IT];           // bn_relu == 3: bn_z is the BN's bit mask (one byte per 16-byte chunk)
   if constexpr (BNB) {
 #pragma unroll
     for (int j = 0; j < VECO; ++j) {
@@ -141,6 +142,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       const size_t goff = ok ? ((size_t)m * p.ldc + ncol) * sizeof(TOut) : 0;
       px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
       if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);
+      pbits[i] = p.bn_relu == 3 ? reinterpret_cast<const uint8_t*>(p.bn_z)[goff / 16] : 0u;
     }
   }
 #pragma unroll
@@ -198,6 +200,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
           float d = v.get(j);
           const float xv = xb.get(j);
           if (p.bn_relu == 1 && !(zb.get(j) > 0.f)) d = 0.f;
+          if (p.bn_relu == 3 && !((pbits[i] >> j) & 1u)) d = 0.f;
           if (p.bn_relu == 2 && !(to_float(from_float<TOut>(bsc[j] * xv + bsh[j])) > 0.f)) d = 0.f;
           s1[j] += d;
           s2[j] += d * ((xv - bmu[j]) * bis[j]);
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 // Needs: taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (same x0 for all groups), SX == 1, the output
 // grid as wide as the gathered image, Cred % BK == 0, operands addressable with 32 bits.
 // One LDS stage (the next stage waits in registers): 41 KB for 128x128x64B, three workgroups per CU.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB>
 __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams p) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
@@ -624,10 +627,10 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
     }
   }
 
-  igemm_epilogue<TOut, BM, BN, false>(p, acc, smem, m0, n0, mt);
+  igemm_epilogue<TOut, BM, BN, BNB>(p, acc, smem, m0, n0, mt);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB = false>
 void launch_row3(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + 2 + 3 * BN) * LDR;
@@ -635,7 +638,7 @@ void launch_row3(const IgemmParams& p, hipStream_t stream) {
   constexpr int red_bytes = 4 * 2 * BN * 4;
   constexpr int lds = stage_bytes > epi_bytes ? (stage_bytes > red_bytes ? stage_bytes : red_bytes)
                                               : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
-  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB>;
+  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB>;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -947,8 +950,13 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
   const bool aligned = p.Cred % (64 / ES) == 0 && fits32;
   const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
   if constexpr (EXT) {
-    if ((p.flags & kIgemmRow3) && !(p.flags & kIgemmBnBwd) && aligned && g_force_cfg < 0 && g_row3_mode != 0 &&
+    if ((p.flags & kIgemmRow3) && aligned && g_force_cfg < 0 && g_row3_mode != 0 &&
         p.ntaps % 3 == 0 && p.SX == 1 && (int)p.div_ow.d == p.IW) {
+      if (p.flags & kIgemmBnBwd) {           // data-gradient launch that also reduces the producing BN's backward sums
+        if (p.N > 64) launch_row3<T, TOut, 128, 128, 64, 2, true>(p, stream);
+        else launch_row3<T, TOut, 128, 64, 64, 3, true>(p, stream);
+        return;
+      }
       // measured (scratch/row3_check.py, batch 1024): 64-byte K tiles win up to 256 channels, 128-byte from 512
       const bool k128 = p.Cred % (128 / ES) == 0 && (g_row3_mode == 2 || (g_row3_mode < 0 && p.Cred * ES >= 1024));
       if (p.N > 64) {
@@ -1034,7 +1042,8 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
   if (p.stats != nullptr && out_dtype != dtype)
     throw std::invalid_argument("igemm: stats need out dtype == in dtype");
   if (p.flags & kIgemmBnBwd) {
-    if (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || (p.bn_relu == 1 && p.bn_z == nullptr))
+    if (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr ||
+        ((p.bn_relu == 1 || p.bn_relu == 3) && p.bn_z == nullptr))
       throw std::invalid_argument("igemm: fused BN-backward reduction needs stats slab, bn_x, bn_coef (and bn_z)");
     if (p.N % veco != 0 || p.ldc != p.N)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs dense rows of whole 16-byte chunks");

@@ -374,7 +374,7 @@ class _ConvFn(torch.autograd.Function):
             bnred = None
             if ctx.bnsrc is not None and ctx.bnsrc.uses == 1:      # sole consumer of that BN's output
                 src = ctx.bnsrc
-                bnred = (src.x, x if src.mode == 1 else None, src.coef, src.mode)
+                bnred = (src.x, x if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode)
             dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
                             accum_mask=amask)
         elif dalias is not None:
@@ -387,9 +387,9 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
-# Off by default: measured on MI355X (ResNet-50, batch 256) the fused epilogue costs the data-gradient kernels
-# what the stand-alone reduce kernel took (27.85 vs 27.65 ms/step, profiles/r1_notes.md); kept for smaller
-# batches / future epilogue work.  DPA_FUSE_BN_BWD=1 enables it.
+# Fused BN-backward reduction in the data-gradient epilogue (DPA_FUSE_BN_BWD=0 disables).  First measured a wash
+# (27.85 vs 27.65 ms/step at batch 256: the epilogue paid what the reduce kernel took); with streaming stores, the
+# bit-mask ReLU and batch 1024 it is worth +0.6 % (profiles/r1_notes.md), so it is on.
 # Side stream for weight gradients (single-process runs; see _ConvFn.backward).  join_side_stream() orders the
 # current stream after everything enqueued there -- called before the optimizer reads the gradients.
 _WGRAD_STREAM = os.environ.get("DPA_WGRAD_STREAM", "0") == "1"
@@ -409,7 +409,7 @@ def join_side_stream() -> None:
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
-_FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "0") == "1"
+_FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") == "1"
 # data_ptr of a freshly produced data gradient -> (partial slab, data_ptr of the BN input it was reduced
 # against, tensor version).  BatchNorm backward uses the slab only if the gradient it receives is that very
 # tensor, unmodified: autograd sums gradients of a multiply-used tensor either out of place (new data_ptr)
@@ -428,10 +428,10 @@ bn_bwd_counts = {"fused": 0, "reduced": 0}      # how BatchNorm backward obtaine
 class _BnSrc:
     """Attached (as ``_dpa_bn``) to the output of a training-mode BatchNorm: what a consuming convolution needs
     to reduce that BN's backward sums inside its data-gradient epilogue."""
-    __slots__ = ("x", "coef", "mode", "uses")
+    __slots__ = ("x", "coef", "mode", "uses", "mask")
 
-    def __init__(self, x, coef, mode):
-        self.x, self.coef, self.mode, self.uses = x, coef, mode, 0
+    def __init__(self, x, coef, mode, mask=None):
+        self.x, self.coef, self.mode, self.uses, self.mask = x, coef, mode, 0, mask
 
 
 def apply_bit_mask(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -816,7 +816,7 @@ class _BNFn(torch.autograd.Function):
         # element (1/16 of the output's bytes) and backward reads that instead of the output tensor
         relu_mode = 0 if not relu else (1 if residual is not None else 2)
         mask = None
-        if relu_mode == 1 and not clip and not _FUSE_BN_BWD and _BN_BITMASK:
+        if relu_mode == 1 and not clip and _BN_BITMASK:
             relu_mode = 3
             mask = torch.empty(x.numel() // _vec(x.dtype), dtype=torch.uint8, device=dev)
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
@@ -833,7 +833,7 @@ class _BNFn(torch.autograd.Function):
         ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and residual.shape == x.shape and residual.dtype == x.dtype
                             and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)))
         ctx.cfg = (relu_mode | clip, residual is not None, group, count)
-        _BNFn.last = None if (clip or relu_mode == 3) else _BnSrc(x, coef, relu_mode)
+        _BNFn.last = None if clip else _BnSrc(x, coef, relu_mode, mask)
         return y
 
     @staticmethod

@@ -25,5 +25,5 @@ for n in res[0]:
     a, b = res[0][n], res[1][n]
     rel = float((a - b).norm() / (a.norm() + 1e-12))
     worst = max(worst, rel)
-    if rel > 1e-2: print("DIFF", n, rel)
+    if rel > 1e-2: print("DIFF", n, rel, float(a.norm()), float((a-b).abs().max()))
 print("worst rel diff", worst)

@@ -143,11 +143,17 @@ def test_peer_memory_allreduce_between_processes_sharing_the_gpu(world, tmp_path
     import _dist_workers as W
     from distributed_pytorch_amd import launch
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    launch.spawn(W.p2p_allreduce, world, (world, port, str(tmp_path)))
+    for attempt in range(3):           # the probed port can be taken again before rank 0 binds it
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        try:
+            launch.spawn(W.p2p_allreduce, world, (world, port, str(tmp_path)))
+            break
+        except launch.ProcessFailure as exc:
+            if "Address already in use" not in str(exc) or attempt == 2:
+                raise
     for r in range(world):
         out = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True)
         assert out["status"] == 0 and out["bad"] == [] and out["calls"] == 306 and out["routed"], out

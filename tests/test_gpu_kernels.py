@@ -330,7 +330,7 @@ def test_loss_scaler_overflow_skips_step():
     assert abs(p.detach()[0].item() - (1 - 0.1 * 1 - 0.1 * 1.9)) < 1e-5
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("k,with_accum", [(1, False), (3, True)])
 def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     """The data-gradient epilogue's fused BatchNorm-backward partial sums equal the stand-alone reduce kernel
@@ -346,11 +346,14 @@ def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     coef = torch.stack([torch.randn(Cin, device=DEV) * 0.1, torch.rand(Cin, device=DEV) + 0.5,
                         torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.2]).contiguous()
     z = torch.randn(N, H, H, Cin, device=DEV).to(dt)                              # BN output (mask source, mode 1)
+    if mode == 3:     # the mask as the BN apply pass stores it: one byte per 8 elements, bit j = (z_j > 0)
+        bits = (z.view(-1, 8) > 0).to(torch.uint8) << torch.arange(8, device=DEV, dtype=torch.uint8)
+        z = bits.sum(1).to(torch.uint8).contiguous()
     accum = torch.randn(N, H, H, Cin, device=DEV).to(dt) if with_accum else None
     p = k // 2
     hip_ops._pending_bnred.clear()
     dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum,
-                            bnred=(bn_x, z if mode == 1 else None, coef, mode))
+                            bnred=(bn_x, z if mode in (1, 3) else None, coef, mode))
     slab, xptr, _ = hip_ops._pending_bnred.pop(dx.data_ptr())
     assert xptr == bn_x.data_ptr()
     ref_dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum)
@@ -363,7 +366,7 @@ def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     M = N * H * H
     nblk = C.bn_partial_rows(M, Cin)
     part = torch.empty(nblk, 2, Cin, device=DEV)
-    C.bn_bwd_reduce(dx.data_ptr(), bn_x.data_ptr(), z.data_ptr() if mode == 1 else 0, M, Cin, hip_ops._dt(dx),
+    C.bn_bwd_reduce(dx.data_ptr(), bn_x.data_ptr(), z.data_ptr() if mode in (1, 3) else 0, M, Cin, hip_ops._dt(dx),
                     coef[0].data_ptr(), coef[1].data_ptr(), mode, coef[2].data_ptr(), coef[3].data_ptr(),
                     part.data_ptr(), nblk, torch.cuda.current_stream().cuda_stream)
     got, want = slab.sum(0), part.sum(0)
