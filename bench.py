@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=None)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("DPA_BENCH_GRAPH", "0")))
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="1-GPU rehearsal of the multi-GPU path: process group of one rank + DDP wrapper + RCCL reducer")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -58,7 +60,16 @@ def main():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # the input copy stream is created first so it gets a hardware queue of its own (see data.prefetcher.copy_stream)
+    from distributed_pytorch_amd.data.prefetcher import copy_stream as _copy_stream
+
+    copy_stream = _copy_stream(device) if os.environ.get("DPA_EARLY_COPY_STREAM", "1") == "1" else torch.cuda.Stream(device)
+    ddp = world > 1 or args.force_ddp
+    if ddp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ["DPA_FORCE_NATIVE_REDUCER"] = "1"      # a single rank would otherwise skip the reducer
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank,
                                 device_id=device)
 
@@ -80,7 +91,7 @@ def main():
         from distributed_pytorch_amd.parallel import convert_syncbn_model
 
         model = convert_syncbn_model(model)
-    if world > 1:
+    if ddp:
         from distributed_pytorch_amd.parallel import DistributedDataParallel
 
         kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
@@ -94,7 +105,8 @@ def main():
     base = getattr(model, "module", model)
     pre = StreamPrefetcher(data, device, dtype=amp.compute_dtype(torch.float32),
                            pad_c=0 if F._TORCH_BASELINE else 8,
-                           s2d=bool(getattr(base, "stem_s2d", False)) and not F._TORCH_BASELINE)
+                           s2d=bool(getattr(base, "stem_s2d", False)) and not F._TORCH_BASELINE,
+                           stream=copy_stream)
 
     graphed = None
     if args.graph and world == 1 and not F._TORCH_BASELINE:
@@ -117,19 +129,19 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss.item())
@@ -148,12 +160,13 @@ def main():
             "final_loss": final_loss,
             "config": {"model": args.arch, "global_batch": args.batch_size * world,
                        "per_gpu_batch": args.batch_size, "seq_len": None, "image_size": args.image_size,
-                       "parallelism": "dp%d" % world, "optimizer": "sgd+momentum+wd (fused)",
+                       "parallelism": "dp%d" % world + (" (forced DDP path)" if args.force_ddp and world == 1 else ""),
+                       "optimizer": "sgd+momentum+wd (fused)",
                        "amp": "O2 " + args.dtype if args.dtype != "fp32" else "O0",
                        "hip_graph": bool(graphed is not None and graphed.replays > 0),
                        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
         }), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

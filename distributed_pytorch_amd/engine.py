@@ -97,6 +97,9 @@ def main_worker(local_rank: int, ngpus_per_node: int, args) -> None:
     if use_gpu:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
+        from .data.prefetcher import copy_stream
+
+        copy_stream(device)       # first stream of the process: a hardware queue of its own for the input copies
         # reference: nd_imagenet.py:120-121 (only with --gpu), imagenet_ddp.py:97 (every worker)
         if script == "ddp" or (script == "nd" and getattr(args, "gpu", None) is not None):
             print("Use GPU: {} for training".format(local_rank), flush=True)
