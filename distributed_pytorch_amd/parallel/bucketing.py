@@ -36,9 +36,29 @@ class BucketSpec:
 
 def plan_buckets(numels: Sequence[int], elem_sizes: Sequence[int], dtype_keys: Sequence[int],
                  order: Sequence[int], cap_bytes: int, first_cap_bytes: int,
-                 align_bytes: int = 256) -> List[BucketSpec]:
+                 align_bytes: int = 256, last_cap_bytes: int = 0) -> List[BucketSpec]:
     """``order`` = parameter indices in expected ready order.  Returns buckets in
-    the order they are expected to complete."""
+    the order they are expected to complete.
+
+    ``last_cap_bytes`` > 0: the parameters that become ready LAST (the first layers) are kept out of the big
+    buckets and form a final bucket of at most that size -- its all-reduce is the only one that cannot overlap
+    with backward, so it must be short (ResNet-50 with 64 MiB buckets otherwise ends on a 34 MB all-reduce)."""
+    if last_cap_bytes > 0 and len(order) > 1:
+        tail, acc = [], 0
+        for pid in reversed(list(order)):
+            sz = numels[pid] * elem_sizes[pid]
+            if tail and acc + sz > last_cap_bytes:
+                break
+            tail.append(pid)
+            acc += sz
+        head = list(order)[:len(order) - len(tail)]
+        if head:
+            tail.reverse()
+            out = plan_buckets(numels, elem_sizes, dtype_keys, head, cap_bytes, first_cap_bytes, align_bytes)
+            out += plan_buckets(numels, elem_sizes, dtype_keys, tail, 1 << 62, 1 << 62, align_bytes)
+            for i, b in enumerate(out):
+                b.index = i
+            return out
     try:
         from .. import backend
 

@@ -66,7 +66,8 @@ class GradArena:
     """Flat gradient buckets; installs a gradient sink on every parameter."""
 
     def __init__(self, params: List[nn.Parameter], cap_bytes: int = 1 << 62, first_cap_bytes: int = 1 << 62,
-                 order: Optional[List[int]] = None, single_bucket: bool = False, on_ready=None):
+                 order: Optional[List[int]] = None, single_bucket: bool = False, on_ready=None,
+                 last_cap_bytes: int = 0):
         self.params = list(params)
         self.epoch = 0
         n = len(self.params)
@@ -75,8 +76,9 @@ class GradArena:
         keys = [dtypes.index(p.dtype) for p in self.params]
         if single_bucket:
             cap_bytes = first_cap_bytes = 1 << 62
+            last_cap_bytes = 0
         specs = plan_buckets([p.numel() for p in self.params], [p.element_size() for p in self.params],
-                             keys, order, cap_bytes, first_cap_bytes)
+                             keys, order, cap_bytes, first_cap_bytes, last_cap_bytes=last_cap_bytes)
         self.buckets: List[_Bucket] = []
         self.bucket_of: Dict[int, int] = {}
         self.view_of: Dict[int, torch.Tensor] = {}
@@ -227,7 +229,7 @@ class _NativeReducer:
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
-                 bucket_cap_mb: float = 64.0, first_bucket_mb: float = 4.0,
+                 bucket_cap_mb: float = 64.0, first_bucket_mb: float = 4.0, last_bucket_mb: float = 2.0,
                  delay_allreduce: bool = False, broadcast_buffers: bool = True,
                  comm: str = "auto", chunk_mb: float = 128.0, verify_shapes: bool = True):
         super().__init__()
@@ -258,7 +260,8 @@ class DistributedDataParallel(nn.Module):
         self._callback_queued = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes,
-                               single_bucket=delay_allreduce, on_ready=self._on_sink_ready)
+                               single_bucket=delay_allreduce, on_ready=self._on_sink_ready,
+                               last_cap_bytes=int(last_bucket_mb * MiB))
         import os as _os
 
         force = _os.environ.get("DPA_FORCE_NATIVE_REDUCER", "0") == "1"     # world_size 1 test hook

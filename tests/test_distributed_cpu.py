@@ -31,6 +31,11 @@ def test_bucket_planner_caps_order_and_alignment():
     assert [s.param_ids for s in specs] == [[4], [3], [2, 1, 0]]          # small first bucket, oversize alone
     for s in specs:
         assert all(off * 4 % 256 == 0 for off in s.offsets) and s.total >= sum(s.numels)
+    # the parameters that become ready last form a small final bucket (its all-reduce cannot overlap with backward)
+    from distributed_pytorch_amd.parallel.bucketing import plan_buckets
+    tail = plan_buckets([1000] * 10, [4] * 10, [0] * 10, list(range(9, -1, -1)), cap_bytes=1 << 30,
+                        first_cap_bytes=1 << 30, last_cap_bytes=9000)
+    assert [s.param_ids for s in tail] == [[9, 8, 7, 6, 5, 4, 3, 2], [1, 0]] and [s.index for s in tail] == [0, 1]
     mixed = plan_buckets_py([10, 10, 10], [4, 2, 4], [0, 1, 0], [2, 1, 0], 1 << 30, 1 << 30)
     assert sorted(tuple(s.param_ids) for s in mixed) == [(1,), (2, 0)]    # buckets are dtype-homogeneous
     assert chunk_ranges(10, 4, 16) == [(0, 4), (4, 8), (8, 10)]
