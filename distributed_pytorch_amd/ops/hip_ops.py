@@ -370,10 +370,10 @@ class _ConvFn(torch.autograd.Function):
             if dw is not None:              # handed back to autograd on the main stream
                 torch.cuda.current_stream().wait_stream(side)
             wgrad_done = True
+        src, ctx.bnsrc = ctx.bnsrc, None           # drop the reference: it pins the BN's input until the graph dies
         if ctx.needs_input_grad[0] and needs_input_grad:
             bnred = None
-            if ctx.bnsrc is not None and ctx.bnsrc.uses == 1:      # sole consumer of that BN's output
-                src = ctx.bnsrc
+            if src is not None and src.uses == 1:                  # sole consumer of that BN's output
                 bnred = (src.x, x if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode)
             dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
                             accum_mask=amask)
