@@ -95,6 +95,12 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
       qoff[i] = (uint32_t)(((uint32_t)(m_begin + (tid + i * NT) / CPQ) * (uint32_t)p.ldx + kcol) * sizeof(T));
   }
   const uint32_t pstep = (uint32_t)(BKP * p.ldy * (int)sizeof(T)), qstep = (uint32_t)(BKP * p.ldx * (int)sizeof(T));
+  // generic gather: incremental pixel coordinates of the rows this thread stages
+  const int OWg = (int)p.div_ow.d, OHg = (int)(p.div_ohow.d / p.div_ow.d);
+  const int step_n = BKP / (OHg * OWg), step_r = BKP - step_n * OHg * OWg;
+  const int step_oy = step_r / OWg, step_ox = step_r - step_oy * OWg;
+  int qn_[Q_IT], qoy_[Q_IT], qox_[Q_IT];
+  int q_next = -1;
   auto load_tile = [&](int m_base, auto set_c) {
     constexpr int S = decltype(set_c)::value;
     if (LIN) {
@@ -115,30 +121,43 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
       }
       return;
     }
+    // Generic gather.  Like the linear path: unconditional loads (invalid rows read offset 0) with the masks applied
+    // at the LDS write -- a select right behind the load would make the wave wait for it before the MFMAs of the
+    // tile in flight.  The (image, row, column) of every staged pixel advances incrementally from tile to tile
+    // (tiles are requested in order); the two divisions per row per tile made this loop issue bound.
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const int row = (tid + i * NT) / CPP;
       const int m = m_base + row;
       const bool ok = pok && m < m_end;
-      rp[S][i] = ok ? *reinterpret_cast<const uint4*>(Yg + ((size_t)m * p.ldy + i0 + cp * VEC) * sizeof(T))
-                    : make_uint4(0, 0, 0, 0);
+      pmask[S][i] = ok ? 0xffffffffu : 0u;
+      rp[S][i] = *reinterpret_cast<const uint4*>(Yg + (ok ? ((size_t)m * p.ldy + i0 + cp * VEC) * sizeof(T) : (size_t)0));
     }
+    if (m_base != q_next) {                     // (re)seed the incremental coordinates
 #pragma unroll
-    for (int i = 0; i < Q_IT; ++i) {
-      const int row = (tid + i * NT) / CPQ;
-      const uint32_t m = m_base + row;
-      bool ok = qok && (int)m < m_end;
-      size_t off = 0;
-      if (ok) {
+      for (int i = 0; i < Q_IT; ++i) {
+        const uint32_t m = (uint32_t)(m_base + (tid + i * NT) / CPQ);
         const uint32_t n = fdiv(m, p.div_ohow);
         const uint32_t rem = m - n * p.div_ohow.d;
         const uint32_t oy = fdiv(rem, p.div_ow);
-        const uint32_t ox = rem - oy * p.div_ow.d;
-        const int iy = (int)oy * p.SY + qdy, ix = (int)ox * p.SX + qdx;
-        ok = (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-        off = ((size_t)((int)n * p.IH * p.IW + iy * p.IW + ix) * p.ldx + qc) * sizeof(T);
+        qn_[i] = (int)n; qoy_[i] = (int)oy; qox_[i] = (int)(rem - oy * p.div_ow.d);
       }
-      rq[S][i] = ok ? *reinterpret_cast<const uint4*>(Xg + off) : make_uint4(0, 0, 0, 0);
+    }
+    q_next = m_base + BKP;
+#pragma unroll
+    for (int i = 0; i < Q_IT; ++i) {
+      const int m = m_base + (tid + i * NT) / CPQ;
+      const int iy = qoy_[i] * p.SY + qdy, ix = qox_[i] * p.SX + qdx;
+      const bool ok = qok && m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      const size_t off = ((size_t)((qn_[i] * p.IH + iy) * p.IW + ix) * p.ldx + qc) * sizeof(T);
+      qmask[S][i] = ok ? 0xffffffffu : 0u;
+      rq[S][i] = *reinterpret_cast<const uint4*>(Xg + (ok ? off : (size_t)0));
+      // advance by BKP pixels: BKP = step_oy * OW + step_ox, at most one image wrap (host checks OH*OW >= BKP,
+      // otherwise step_n carries whole images and the loop below still terminates after <= 2 trips)
+      int ox = qox_[i] + step_ox, oy = qoy_[i] + step_oy, n = qn_[i] + step_n;
+      if (ox >= OWg) { ox -= OWg; ++oy; }
+      while (oy >= OHg) { oy -= OHg; ++n; }
+      qox_[i] = ox; qoy_[i] = oy; qn_[i] = n;
     }
   };
   auto store_tile = [&](int buf, auto set_c) {
@@ -149,14 +168,14 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
     for (int i = 0; i < P_IT; ++i) {
       const int row = (tid + i * NT) / CPP;
       uint4 v = rp[S][i];
-      if (LIN) { v.x &= pmask[S][i]; v.y &= pmask[S][i]; v.z &= pmask[S][i]; v.w &= pmask[S][i]; }
+      v.x &= pmask[S][i]; v.y &= pmask[S][i]; v.z &= pmask[S][i]; v.w &= pmask[S][i];
       *reinterpret_cast<uint4*>(sp + row * LDP + cp * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < Q_IT; ++i) {
       const int row = (tid + i * NT) / CPQ;
       uint4 v = rq[S][i];
-      if (LIN) { v.x &= qmask[S][i]; v.y &= qmask[S][i]; v.z &= qmask[S][i]; v.w &= qmask[S][i]; }
+      v.x &= qmask[S][i]; v.y &= qmask[S][i]; v.z &= qmask[S][i]; v.w &= qmask[S][i];
       *reinterpret_cast<uint4*>(sq + row * LDQ + cq * 16) = v;
     }
   };
