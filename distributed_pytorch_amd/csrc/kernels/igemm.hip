@@ -377,13 +377,15 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
       const int iy = iy0[i] + dy, ix = ix0[i] + dx;
       const bool ok = tok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
       const size_t off = ((size_t)(pbase[i] + iy * p.IW + ix) * p.lda + cA) * sizeof(T);
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(Ag + off) : make_uint4(0, 0, 0, 0);
+      // unconditional load + mask at the LDS write (a select behind the load makes the wave wait for it here)
+      amask[i] = ok ? 0xffffffffu : 0u;
+      ra[i] = *reinterpret_cast<const uint4*>(Ag + (ok ? off : (size_t)0));
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const bool ok = tok && bok[i];
-      rb[i] = ok ? *reinterpret_cast<const uint4*>(Bg + (brow[i] + kB) * sizeof(T))
-                 : make_uint4(0, 0, 0, 0);
+      bmask[i] = ok ? 0xffffffffu : 0u;
+      rb[i] = *reinterpret_cast<const uint4*>(Bg + (ok ? (brow[i] + kB) * sizeof(T) : (size_t)0));
     }
   };
   auto store_tile = [&](int buf) {
@@ -393,14 +395,14 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
     for (int i = 0; i < A_IT; ++i) {
       const int row = (tid + i * 256) / CPR;
       uint4 v = ra[i];
-      if (ALIGNED) { v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i]; }
+      v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
       *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = (tid + i * 256) / CPR;
       uint4 v = rb[i];
-      if (ALIGNED) { v.x &= bmask[i]; v.y &= bmask[i]; v.z &= bmask[i]; v.w &= bmask[i]; }
+      v.x &= bmask[i]; v.y &= bmask[i]; v.z &= bmask[i]; v.w &= bmask[i];
       *reinterpret_cast<uint4*>(sb + row * LDR + ch * 16) = v;
     }
   };
