@@ -28,9 +28,12 @@
 #include <pybind11/stl.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 namespace py = pybind11;
@@ -304,9 +307,96 @@ class BucketReducer {
   int launched_ = 0;
 };
 
+
+// ---- bucket planner (host logic of the reducer) ----------------------------------------------------
+// Packs parameters, given in expected gradient-ready order, into dtype-homogeneous flat buckets.  The first
+// bucket of each dtype is small (its all-reduce starts early), the parameters that become ready LAST form a
+// small bucket of their own (its all-reduce is the only one that cannot overlap with backward), everything
+// in between fills `cap_bytes` buckets sized for xGMI.  Every view offset is aligned to `align_bytes`.
+struct PlannedBucket {
+  long dtype_key = 0;
+  std::vector<long> pids, offsets;
+  long total = 0;     // elements, padded
+};
+
+void plan_range(const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
+                const std::vector<long>& order, size_t begin, size_t end, long cap, long first_cap, long align,
+                std::vector<PlannedBucket>& out) {
+  std::vector<std::pair<long, int>> open;       // dtype -> index into out (few dtypes: linear search)
+  std::vector<long> first_done;
+  auto find_open = [&](long dk) -> int* {
+    for (auto& kv : open)
+      if (kv.first == dk) return &kv.second;
+    return nullptr;
+  };
+  auto done = [&](long dk) {
+    for (long d : first_done)
+      if (d == dk) return true;
+    return false;
+  };
+  for (size_t i = begin; i < end; ++i) {
+    const long pid = order[i];
+    const long dk = dkeys[pid], es = esz[pid], n = numels[pid];
+    int* cur = find_open(dk);
+    const long limit = done(dk) ? cap : first_cap;
+    if (cur != nullptr && *cur >= 0 && !out[*cur].pids.empty() && out[*cur].total * es + n * es > limit) {
+      if (!done(dk)) first_done.push_back(dk);
+      *cur = -1;
+    }
+    if (cur == nullptr) {
+      open.emplace_back(dk, -1);
+      cur = &open.back().second;
+    }
+    if (*cur < 0) {
+      out.emplace_back();
+      out.back().dtype_key = dk;
+      *cur = (int)out.size() - 1;
+    }
+    PlannedBucket& b = out[*cur];
+    b.pids.push_back(pid);
+    b.offsets.push_back(b.total);
+    const long align_el = std::max<long>(1, align / es);
+    b.total += (n + align_el - 1) / align_el * align_el;
+  }
+}
+
+std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> plan_buckets(
+    const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
+    const std::vector<long>& order, long cap, long first_cap, long align, long last_cap) {
+  if (numels.size() != esz.size() || numels.size() != dkeys.size())
+    throw std::invalid_argument("plan_buckets: per-parameter lists differ in length");
+  for (long pid : order)
+    if (pid < 0 || (size_t)pid >= numels.size()) throw std::invalid_argument("plan_buckets: bad parameter index");
+  for (long e : esz)
+    if (e <= 0) throw std::invalid_argument("plan_buckets: bad element size");
+  std::vector<PlannedBucket> out;
+  size_t split = order.size();
+  if (last_cap > 0 && order.size() > 1) {
+    long acc = 0;
+    while (split > 0) {
+      const long pid = order[split - 1];
+      const long sz = numels[pid] * esz[pid];
+      if (split < order.size() && acc + sz > last_cap) break;
+      acc += sz;
+      --split;
+    }
+    if (split == 0) split = order.size();       // everything fits the tail: plan normally
+  }
+  plan_range(numels, esz, dkeys, order, 0, split, cap, first_cap, align, out);
+  const long inf = 1L << 62;
+  plan_range(numels, esz, dkeys, order, split, order.size(), inf, inf, align, out);
+  std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> res;
+  res.reserve(out.size());
+  for (auto& b : out) res.emplace_back(b.dtype_key, std::move(b.pids), std::move(b.offsets), b.total);
+  return res;
+}
+
 }  // namespace
 
 void bind_comm(py::module_& m) {
+  m.def("plan_buckets", &plan_buckets, py::arg("numels"), py::arg("elem_sizes"), py::arg("dtype_keys"),
+        py::arg("order"), py::arg("cap_bytes"), py::arg("first_cap_bytes"), py::arg("align_bytes") = 256,
+        py::arg("last_cap_bytes") = 0);
   m.def("rccl_version", &Communicator::version);
   m.def("rccl_unique_id", &Communicator::unique_id);
   py::class_<Communicator, std::shared_ptr<Communicator>>(m, "Communicator")

@@ -13,7 +13,7 @@ small.  One tensor bigger than the cap (VGG-16 ``fc6.weight`` = 392 MiB) becomes
 bucket of its own and is all-reduced in ``chunk_bytes`` slices so its transfer
 pipelines instead of serialising.
 
-The native implementation lives in ``csrc/comm/bucket_planner.cpp``; this Python
+The native implementation is ``plan_buckets`` in ``csrc/comm/comm.cpp``; this Python
 version is the oracle used in tests and the fallback when ``_C`` is not built.
 """
 from __future__ import annotations
@@ -43,39 +43,40 @@ def plan_buckets(numels: Sequence[int], elem_sizes: Sequence[int], dtype_keys: S
     ``last_cap_bytes`` > 0: the parameters that become ready LAST (the first layers) are kept out of the big
     buckets and form a final bucket of at most that size -- its all-reduce is the only one that cannot overlap
     with backward, so it must be short (ResNet-50 with 64 MiB buckets otherwise ends on a 34 MB all-reduce)."""
-    if last_cap_bytes > 0 and len(order) > 1:
-        tail, acc = [], 0
-        for pid in reversed(list(order)):
-            sz = numels[pid] * elem_sizes[pid]
-            if tail and acc + sz > last_cap_bytes:
-                break
-            tail.append(pid)
-            acc += sz
-        head = list(order)[:len(order) - len(tail)]
-        if head:
-            tail.reverse()
-            out = plan_buckets(numels, elem_sizes, dtype_keys, head, cap_bytes, first_cap_bytes, align_bytes)
-            out += plan_buckets(numels, elem_sizes, dtype_keys, tail, 1 << 62, 1 << 62, align_bytes)
-            for i, b in enumerate(out):
-                b.index = i
-            return out
     try:
         from .. import backend
 
         ext = backend.load()
-        if ext is not None and hasattr(ext, "plan_buckets"):
-            raw = ext.plan_buckets(list(numels), list(elem_sizes), list(dtype_keys), list(order),
-                                   int(cap_bytes), int(first_cap_bytes), int(align_bytes))
-            return [BucketSpec(i, dk, list(pids), list(offs), [numels[p] for p in pids], tot)
-                    for i, (dk, pids, offs, tot) in enumerate(raw)]
     except Exception:
-        pass
+        ext = None
+    if ext is not None and hasattr(ext, "plan_buckets"):
+        raw = ext.plan_buckets(list(numels), list(elem_sizes), list(dtype_keys), list(order),
+                               int(cap_bytes), int(first_cap_bytes), int(align_bytes), int(last_cap_bytes))
+        return [BucketSpec(i, dk, list(pids), list(offs), [numels[p] for p in pids], tot)
+                for i, (dk, pids, offs, tot) in enumerate(raw)]
     return plan_buckets_py(numels, elem_sizes, dtype_keys, order, cap_bytes, first_cap_bytes,
-                           align_bytes)
+                           align_bytes, last_cap_bytes)
 
 
 def plan_buckets_py(numels, elem_sizes, dtype_keys, order, cap_bytes, first_cap_bytes,
-                    align_bytes: int = 256) -> List[BucketSpec]:
+                    align_bytes: int = 256, last_cap_bytes: int = 0) -> List[BucketSpec]:
+    """Pure-Python oracle of the native planner (same result, used in tests and without ``_C``)."""
+    order = list(order)
+    if last_cap_bytes > 0 and len(order) > 1:
+        split, acc = len(order), 0
+        while split > 0:
+            sz = numels[order[split - 1]] * elem_sizes[order[split - 1]]
+            if split < len(order) and acc + sz > last_cap_bytes:
+                break
+            acc += sz
+            split -= 1
+        if split > 0:
+            out = plan_buckets_py(numels, elem_sizes, dtype_keys, order[:split], cap_bytes, first_cap_bytes,
+                                  align_bytes)
+            out += plan_buckets_py(numels, elem_sizes, dtype_keys, order[split:], 1 << 62, 1 << 62, align_bytes)
+            for i, b in enumerate(out):
+                b.index = i
+            return out
     buckets: List[BucketSpec] = []
     open_by_dtype: Dict[int, BucketSpec] = {}
     first_done: Dict[int, bool] = {}

@@ -41,6 +41,35 @@ def test_bucket_planner_caps_order_and_alignment():
     assert chunk_ranges(10, 4, 16) == [(0, 4), (4, 8), (8, 10)]
 
 
+def test_native_bucket_planner_equals_python_oracle():
+    """csrc/comm/comm.cpp:plan_buckets against the Python oracle on random parameter lists."""
+    import random
+
+    from distributed_pytorch_amd import backend
+    from distributed_pytorch_amd.parallel.bucketing import plan_buckets
+
+    ext = backend.load()
+    if ext is None or not hasattr(ext, "plan_buckets"):
+        pytest.skip("_C not built")
+    rng = random.Random(0)
+    for trial in range(200):
+        n = rng.randint(1, 40)
+        numels = [rng.choice([1, 7, 64, 1000, 4096, 250000, 3000000]) for _ in range(n)]
+        dk = [rng.choice([0, 0, 0, 1]) for _ in range(n)]
+        es = [4 if k == 0 else 2 for k in dk]
+        order = list(range(n))
+        rng.shuffle(order)
+        cap, first = rng.choice([1 << 12, 1 << 20, 1 << 24, 1 << 40]), rng.choice([1, 1 << 10, 1 << 20, 1 << 40])
+        last = rng.choice([0, 0, 1 << 8, 1 << 14, 1 << 22, 1 << 40])
+        align = rng.choice([16, 256])
+        a = plan_buckets(numels, es, dk, order, cap, first, align, last)
+        b = plan_buckets_py(numels, es, dk, order, cap, first, align, last)
+        assert [(s.index, s.dtype_key, s.param_ids, s.offsets, s.numels, s.total) for s in a] == \
+               [(s.index, s.dtype_key, s.param_ids, s.offsets, s.numels, s.total) for s in b], trial
+    with pytest.raises(Exception):
+        ext.plan_buckets([1], [4], [0], [3], 1, 1, 256, 0)          # parameter index out of range
+
+
 def test_native_store_rendezvous_and_host_collectives(tmp_path):
     """--dist-backend native: C++ TcpStore rendezvous, no torch.distributed anywhere."""
     world = 2
