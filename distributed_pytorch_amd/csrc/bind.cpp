@@ -258,6 +258,23 @@ PYBIND11_MODULE(_C, m) {
   m.def("relu_bwd", [](uintptr_t y, uintptr_t dy, uintptr_t dx, long n, int dtype, uintptr_t s) {
     relu_bwd_launch(ptr<const void>(y), ptr<const void>(dy), ptr<void>(dx), n, dtype, st(s));
   });
+  m.def("add_fwd", [](uintptr_t a, uintptr_t b, uintptr_t y, long n, int dtype, uintptr_t s) {
+    add_fwd_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(y), n, dtype, st(s));
+  });
+  m.def("act_fwd", [](uintptr_t x, uintptr_t y, long n, int act, int dtype, uintptr_t s) {
+    act_fwd_launch(ptr<const void>(x), ptr<void>(y), n, act, dtype, st(s));
+  });
+  m.def("act_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, long n, int act, int dtype, uintptr_t s) {
+    act_bwd_launch(ptr<const void>(x), ptr<const void>(dy), ptr<void>(dx), n, act, dtype, st(s));
+  });
+  m.def("se_scale_fwd", [](uintptr_t x, uintptr_t sc, uintptr_t y, long NB, int HW, int C, int dtype, uintptr_t s) {
+    se_scale_fwd_launch(ptr<const void>(x), ptr<const float>(sc), ptr<void>(y), NB, HW, C, dtype, st(s));
+  });
+  m.def("se_scale_bwd", [](uintptr_t dy, uintptr_t x, uintptr_t sc, uintptr_t dx, uintptr_t ds, long NB, int HW, int C,
+                           int dtype, uintptr_t s) {
+    se_scale_bwd_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const float>(sc), ptr<void>(dx), ptr<float>(ds), NB,
+                        HW, C, dtype, st(s));
+  });
   m.def("add_relu_fwd", [](uintptr_t a, uintptr_t b, uintptr_t y, long n, int dtype, uintptr_t s) {
     add_relu_fwd_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(y), n, dtype, st(s));
   });

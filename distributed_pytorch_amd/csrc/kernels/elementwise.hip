@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const TI* __restrict_
   }
 }
 
-template <typename T, int OP>  // 0: relu, 1: relu_bwd(y, dy), 2: add_relu(a, b)
+template <typename T, int OP>  // 0: relu, 1: relu_bwd(y, dy), 2: add_relu(a, b), 3: a + b
 __global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
                                                  long nchunks) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const 
       float r;
       if (OP == 0) r = fmaxf(va.get(j), 0.f);
       else if (OP == 1) r = va.get(j) > 0.f ? vb.get(j) : 0.f;
-      else r = fmaxf(va.get(j) + vb.get(j), 0.f);
+      else if (OP == 2) r = fmaxf(va.get(j) + vb.get(j), 0.f);
+      else r = va.get(j) + vb.get(j);
       vo.set(j, r);
     }
     vo.store(y + i * VEC);
@@ -124,7 +125,8 @@ __global__ void ew_tail_kernel(const T* a, const T* b, T* y, long begin, long n)
   float r;
   if (OP == 0) r = fmaxf(to_float(a[i]), 0.f);
   else if (OP == 1) r = to_float(a[i]) > 0.f ? to_float(b[i]) : 0.f;
-  else r = fmaxf(to_float(a[i]) + to_float(b[i]), 0.f);
+  else if (OP == 2) r = fmaxf(to_float(a[i]) + to_float(b[i]), 0.f);
+  else r = to_float(a[i]) + to_float(b[i]);
   y[i] = from_float<T>(r);
 }
 
@@ -140,6 +142,133 @@ void ew_launch(const void* a, const void* b, void* y, long n, hipStream_t s) {
     hipLaunchKernelGGL((ew_tail_kernel<T, OP>), dim3(1), dim3(64), 0, s, (const T*)a, (const T*)b, (T*)y,
                        nchunks * VEC, n);
   DPA_CHECK_HIP(hipGetLastError());
+}
+
+
+// ---- smooth activations (EfficientNet / MobileNetV3 / squeeze-excitation gates) -------------------------------
+// act: 1 sigmoid, 2 SiLU (x * sigmoid(x)), 3 hard-sigmoid (relu6(x + 3) / 6), 4 hard-swish (x * hard-sigmoid(x)).
+// Backward recomputes the derivative from the saved INPUT, so no activation-sized mask / output is kept.
+__device__ __forceinline__ float act_value(int act, float x) {
+  switch (act) {
+    case 1: return 1.f / (1.f + __expf(-x));
+    case 2: return x / (1.f + __expf(-x));
+    case 3: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    default: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  }
+}
+__device__ __forceinline__ float act_slope(int act, float x) {
+  switch (act) {
+    case 1: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
+    case 2: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case 3: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
+    default: return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f));   // ATen's convention at +-3
+  }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out,
+                                                  long nchunks, int act) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+    Vec16<T> vx, vg, vo;
+    vx.load(x + i * VEC);
+    if (BWD) vg.load(dy + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float v = vx.get(j);
+      vo.set(j, BWD ? vg.get(j) * act_slope(act, v) : act_value(act, v));
+    }
+    vo.store(out + i * VEC);
+  }
+}
+template <typename T, bool BWD>
+__global__ void act_tail_kernel(const T* x, const T* dy, T* out, long begin, long n, int act) {
+  const long i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = to_float(x[i]);
+  out[i] = from_float<T>(BWD ? to_float(dy[i]) * act_slope(act, v) : act_value(act, v));
+}
+
+template <typename T, bool BWD>
+void act_launch_t(const void* x, const void* dy, void* out, long n, int act, hipStream_t s) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long nchunks = n / VEC;
+  if (nchunks > 0)
+    hipLaunchKernelGGL((act_kernel<T, BWD>), dim3(grid_for(nchunks)), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out,
+                       nchunks, act);
+  const long rem = n - nchunks * VEC;
+  if (rem > 0)
+    hipLaunchKernelGGL((act_tail_kernel<T, BWD>), dim3(1), dim3(64), 0, s, (const T*)x, (const T*)dy, (T*)out,
+                       nchunks * VEC, n, act);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+// ---- per-(sample, channel) scale: squeeze-excitation gate, stochastic depth ("row" mode: s constant over c) -------
+// y[n][p][c] = x[n][p][c] * s[n][c]                                         (s fp32 [N][C])
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                       T* __restrict__ y, long total, int HW, int chunks) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long pix = i / chunks;
+    const int ch = (int)(i - pix * chunks);
+    const long n = pix / HW;
+    const float* sp = s + n * (long)chunks * VEC + ch * VEC;
+    Vec16<T> v, o;
+    v.load(x + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * sp[j]);
+    o.store(y + i * VEC);
+  }
+}
+
+// backward of the gate: dx = dy * s,  ds[n][c] = sum_p dy[n][p][c] * x[n][p][c].  One workgroup owns sample n and
+// 16 chunks of channels; 16 pixel rows of the workgroup stride over H*W and meet in LDS (fixed order: deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ s, T* __restrict__ dx,
+                                                           float* __restrict__ ds, int HW, int chunks) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int CL = 16, PR = 16;
+  __shared__ float red[PR][CL][VEC + 1];
+  const int cl = threadIdx.x % CL, pr = threadIdx.x / CL;
+  const int ch = blockIdx.x * CL + cl;
+  const long n = blockIdx.y;
+  const int C = chunks * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (ch < chunks) {
+    float sv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sv[j] = s[n * C + ch * VEC + j];
+    for (int p = pr; p < HW; p += PR) {
+      const long off = ((n * HW + p) * (long)chunks + ch) * VEC;
+      Vec16<T> g, v, o;
+      g.load(dy + off);
+      v.load(x + off);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float gj = g.get(j);
+        acc[j] += gj * v.get(j);
+        o.set(j, gj * sv[j]);
+      }
+      o.store(dx + off);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[pr][cl][j] = acc[j];
+  __syncthreads();
+  if (ds != nullptr && pr == 0 && ch < chunks) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = 0.f;
+      for (int r = 0; r < PR; ++r) t += red[r][cl][j];
+      ds[n * C + ch * VEC + j] = t;
+    }
+  }
 }
 
 // counter-based RNG (splitmix64 finaliser over (seed, offset + index)): stateless, graph-replayable
@@ -279,6 +408,42 @@ void relu_bwd_launch(const void* yv, const void* dy, void* dx, long n, int dtype
 }
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s) {
   DPA_DISPATCH_DTYPE(dtype, (ew_launch<T, 2>(a, b, y, n, s)));
+}
+
+void add_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s) {
+  DPA_DISPATCH_DTYPE(dtype, (ew_launch<T, 3>(a, b, y, n, s)));
+}
+
+void act_fwd_launch(const void* x, void* y, long n, int act, int dtype, hipStream_t s) {
+  if (act < 1 || act > 4) throw std::invalid_argument("act: unknown activation code");
+  if (n <= 0) return;
+  DPA_DISPATCH_DTYPE(dtype, (act_launch_t<T, false>(x, nullptr, y, n, act, s)));
+}
+void act_bwd_launch(const void* x, const void* dy, void* dx, long n, int act, int dtype, hipStream_t s) {
+  if (act < 1 || act > 4) throw std::invalid_argument("act: unknown activation code");
+  if (n <= 0) return;
+  DPA_DISPATCH_DTYPE(dtype, (act_launch_t<T, true>(x, dy, dx, n, act, s)));
+}
+
+void se_scale_fwd_launch(const void* x, const float* sc, void* y, long NB, int HW, int C, int dtype, hipStream_t s) {
+  const int vec = dtype == kF32 ? 4 : 8;
+  if (C % vec != 0) throw std::invalid_argument("se_scale: C must fill 16-byte vectors");
+  const long total = NB * HW * (C / vec);
+  if (total <= 0) return;
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(se_scale_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, sc,
+                                               (T*)y, total, HW, C / vec));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+void se_scale_bwd_launch(const void* dy, const void* x, const float* sc, void* dx, float* ds, long NB, int HW, int C,
+                         int dtype, hipStream_t s) {
+  const int vec = dtype == kF32 ? 4 : 8;
+  if (C % vec != 0) throw std::invalid_argument("se_scale: C must fill 16-byte vectors");
+  if (NB <= 0 || HW <= 0) return;
+  if (NB > 65535) throw std::invalid_argument("se_scale: batch exceeds grid.y");
+  const int chunks = C / vec;
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(se_scale_bwd_kernel<T>, dim3(ceil_div(chunks, 16), (unsigned)NB), dim3(256),
+                                               0, s, (const T*)dy, (const T*)x, sc, (T*)dx, ds, HW, chunks));
+  DPA_CHECK_HIP(hipGetLastError());
 }
 
 void dropout_fwd_launch(const void* x, void* y, uint8_t* mask, long n, float p, uint64_t seed, uint64_t offset,

@@ -173,6 +173,14 @@ void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad
 void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
 void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
+void add_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
+// act: 1 sigmoid, 2 SiLU, 3 hard-sigmoid, 4 hard-swish; backward recomputes the slope from the input x
+void act_fwd_launch(const void* x, void* y, long n, int act, int dtype, hipStream_t s);
+void act_bwd_launch(const void* x, const void* dy, void* dx, long n, int act, int dtype, hipStream_t s);
+// y[n][p][c] = x[n][p][c] * sc[n][c] (squeeze-excitation gate / stochastic depth); backward: dx and ds = sum_p dy * x
+void se_scale_fwd_launch(const void* x, const float* sc, void* y, long NB, int HW, int C, int dtype, hipStream_t s);
+void se_scale_bwd_launch(const void* dy, const void* x, const float* sc, void* dx, float* ds, long NB, int HW, int C,
+                         int dtype, hipStream_t s);
 // counter (device, optional): RNG stream position read by the kernel and advanced by n afterwards
 void dropout_fwd_launch(const void* x, void* y, uint8_t* mask, long n, float p, uint64_t seed,
                         uint64_t offset, uint64_t* counter, int dtype, hipStream_t s);

@@ -1,11 +1,11 @@
-"""Depthwise-separable families in NHWC: MobileNetV2 and MNASNet 0.5 / 0.75 / 1.0 / 1.3 (torchvision zoo members
+"""Depthwise-separable families in NHWC: MobileNetV2, MobileNetV3 large / small and MNASNet 0.5 / 0.75 / 1.0 / 1.3 (torchvision zoo members
 reachable through the reference's ``models.__dict__[arch]()``, ``nd_imagenet.py:22-24,133-138``).
 
 Module names match torchvision (``features.1.conv.0.0.weight``, ``layers.8.0.layers.3.weight``,
 ``classifier.1.weight``) so its checkpoints load.  A depthwise convolution is the grouped implicit-GEMM kernel
 with groups == channels: 64 consecutive channels share one block-diagonal MFMA tile (``hip_ops.group_merge``),
 one launch per pass.  BN + ReLU6 is the same fused normalise pass as BN + ReLU (activation code 6).  Parameter
-counts: mobilenet_v2 3,504,872; mnasnet0_5 2,218,512; mnasnet0_75 3,170,208; mnasnet1_0 4,383,312;
+counts: mobilenet_v2 3,504,872; mobilenet_v3_large 5,483,032; mobilenet_v3_small 2,542,856; mnasnet0_5 2,218,512; mnasnet0_75 3,170,208; mnasnet1_0 4,383,312;
 mnasnet1_3 6,282,256.
 """
 from __future__ import annotations
@@ -13,7 +13,8 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from ..nn.modules import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Dropout, Linear, ReLU, ReLU6, conv_bn_act
+from ..nn.modules import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Dropout, Hardswish, Linear, ReLU, ReLU6,
+                          SqueezeExcitation, conv_bn_act)
 from .alexnet_vgg import _ImageNetCNN, run_fused_sequential
 
 
@@ -101,6 +102,109 @@ class MobileNetV2(_ImageNetCNN):
 
 def mobilenet_v2(**kw):
     return MobileNetV2(**kw)
+
+
+
+# ------------------------------------------------------------------------------------------ MobileNetV3
+class _ConvBNAct(nn.Sequential):
+    """torchvision's ``Conv2dNormActivation``: 0 conv, 1 norm (, 2 activation: ReLU or Hardswish)."""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, groups=1, act="relu", eps=1e-3, momentum=0.01):
+        layers = [Conv2d(cin, cout, kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=False,
+                         groups=groups), BatchNorm2d(cout, eps=eps, momentum=momentum)]
+        if act == "relu":
+            layers.append(ReLU(inplace=True))
+        elif act == "hardswish":
+            layers.append(Hardswish(inplace=True))
+        elif act is not None:
+            raise ValueError("unsupported activation %r" % (act,))
+        super().__init__(*layers)
+        self.act = act
+
+    def forward(self, x, residual=None):
+        if self.act == "hardswish":
+            return conv_bn_act(x, self[0], self[1], act="hardswish")
+        return conv_bn_act(x, self[0], self[1], relu=self.act == "relu", residual=residual)
+
+
+class _V3InvertedResidual(nn.Module):
+    def __init__(self, cin, kernel, expanded, cout, use_se, act, stride):
+        super().__init__()
+        if stride not in (1, 2):
+            raise ValueError("illegal stride value")
+        self.use_res_connect = stride == 1 and cin == cout
+        layers = []
+        if expanded != cin:
+            layers.append(_ConvBNAct(cin, expanded, 1, act=act))
+        layers.append(_ConvBNAct(expanded, expanded, kernel, stride=stride, groups=expanded, act=act))
+        if use_se:
+            layers.append(SqueezeExcitation(expanded, _make_divisible(expanded // 4, 8), activation="relu",
+                                            scale_activation="hardsigmoid"))
+        layers.append(_ConvBNAct(expanded, cout, 1, act=None))
+        self.block = nn.Sequential(*layers)
+        self.out_channels = cout
+
+    def forward(self, x):
+        mods = list(self.block)
+        h = x
+        for m in mods[:-1]:
+            h = m(h)
+        return mods[-1](h, residual=x if self.use_res_connect else None)     # identity joins inside the BN pass
+
+
+_V3_LARGE = [(16, 3, 16, 16, False, "relu", 1), (16, 3, 64, 24, False, "relu", 2), (24, 3, 72, 24, False, "relu", 1),
+             (24, 5, 72, 40, True, "relu", 2), (40, 5, 120, 40, True, "relu", 1), (40, 5, 120, 40, True, "relu", 1),
+             (40, 3, 240, 80, False, "hardswish", 2), (80, 3, 200, 80, False, "hardswish", 1),
+             (80, 3, 184, 80, False, "hardswish", 1), (80, 3, 184, 80, False, "hardswish", 1),
+             (80, 3, 480, 112, True, "hardswish", 1), (112, 3, 672, 112, True, "hardswish", 1),
+             (112, 5, 672, 160, True, "hardswish", 2), (160, 5, 960, 160, True, "hardswish", 1),
+             (160, 5, 960, 160, True, "hardswish", 1)]
+_V3_SMALL = [(16, 3, 16, 16, True, "relu", 2), (16, 3, 72, 24, False, "relu", 2), (24, 3, 88, 24, False, "relu", 1),
+             (24, 5, 96, 40, True, "hardswish", 2), (40, 5, 240, 40, True, "hardswish", 1),
+             (40, 5, 240, 40, True, "hardswish", 1), (40, 5, 120, 48, True, "hardswish", 1),
+             (48, 5, 144, 48, True, "hardswish", 1), (48, 5, 288, 96, True, "hardswish", 2),
+             (96, 5, 576, 96, True, "hardswish", 1), (96, 5, 576, 96, True, "hardswish", 1)]
+
+
+class MobileNetV3(_ImageNetCNN):
+    def __init__(self, setting, last_channel: int, num_classes: int = 1000, dropout: float = 0.2):
+        super().__init__()
+        stem = _ConvBNAct(3, setting[0][0], 3, stride=2, act="hardswish")
+        stem[0].needs_input_grad = False
+        layers = [stem] + [_V3InvertedResidual(*cfg) for cfg in setting]
+        cin = setting[-1][3]
+        layers.append(_ConvBNAct(cin, 6 * cin, 1, act="hardswish"))
+        self.features = nn.Sequential(*layers)
+        self.avgpool = AdaptiveAvgPool2d(1)
+        self.classifier = nn.Sequential(Linear(6 * cin, last_channel), Hardswish(inplace=True), Dropout(dropout),
+                                        Linear(last_channel, num_classes))
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.prepare_input(x)
+        x = self.features(x)
+        x = self.avgpool(x)
+        c = self.classifier
+        x = c[2](c[1](c[0](x.reshape(x.shape[0], -1))))
+        return c[3](x, out_dtype=torch.float32)
+
+
+def mobilenet_v3_large(**kw):
+    return MobileNetV3(_V3_LARGE, 1280, **kw)
+
+
+def mobilenet_v3_small(**kw):
+    return MobileNetV3(_V3_SMALL, 1024, **kw)
 
 
 # ------------------------------------------------------------------------------------------ MNASNet

@@ -1,4 +1,4 @@
-"""RegNetX 400MF ... 32GF in NHWC (torchvision zoo members reachable through the reference's
+"""RegNetX 400MF ... 32GF and RegNetY 400MF ... 128GF in NHWC (torchvision zoo members reachable through the reference's
 ``models.__dict__[arch]()``, ``nd_imagenet.py:22-24,133-138``).
 
 Stage widths / depths come from the RegNet design-space quantisation (linear width ramp ``w_0 + w_a * i`` snapped to
@@ -8,7 +8,11 @@ parameter counts equal its checkpoints: x_400mf 5,495,976; x_800mf 7,259,656; x_
 x_8gf 39,572,648; x_16gf 54,278,536; x_32gf 107,811,560.
 
 The 3x3 of every block is a grouped convolution (group width 16 ... 168 channels): one launch of the implicit-GEMM
-kernel with the group on ``grid.y``.  The Y variants (squeeze-excitation) are not part of this zoo.
+kernel with the group on ``grid.y``.
+
+The Y variants add a squeeze-excitation gate between the grouped 3x3 and the last 1x1 (``f.se.fc1.weight`` ...):
+y_400mf 4,344,144; y_800mf 6,432,512; y_1_6gf 11,202,430; y_3_2gf 19,436,338; y_8gf 39,381,472; y_16gf 83,590,140;
+y_32gf 145,046,770; y_128gf 644,812,894 parameters.
 """
 from __future__ import annotations
 
@@ -18,7 +22,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
-from ..nn.modules import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Linear, ReLU, conv_bn_act
+from ..nn.modules import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Linear, ReLU, SqueezeExcitation, conv_bn_act
 from .alexnet_vgg import _ImageNetCNN
 
 
@@ -27,8 +31,9 @@ def _make_divisible(v: float, divisor: int) -> int:
     return new_v + divisor if new_v < 0.9 * v else new_v
 
 
-def block_params(depth: int, w_0: int, w_a: float, w_m: float, group_width: int, bottleneck_multiplier: float = 1.0):
-    """-> per stage: (width_out, stride, depth, group_width, bottleneck_multiplier)."""
+def block_params(depth: int, w_0: int, w_a: float, w_m: float, group_width: int, bottleneck_multiplier: float = 1.0,
+                 se_ratio=None):
+    """-> per stage: (width_out, stride, depth, group_width, bottleneck_multiplier[, se_ratio])."""
     quant = 8
     if w_a < 0 or w_0 <= 0 or w_m <= 1 or w_0 % 8 != 0:
         raise ValueError("Invalid RegNet settings")
@@ -48,7 +53,8 @@ def block_params(depth: int, w_0: int, w_a: float, w_m: float, group_width: int,
     gws = [min(g, wb) for g, wb in zip(gws, bot)]
     bot = [_make_divisible(wb, g) for wb, g in zip(bot, gws)]
     stage_widths = [int(wb / b) for wb, b in zip(bot, mult)]
-    return list(zip(stage_widths, [2] * num_stages, stage_depths, gws, mult))
+    out = list(zip(stage_widths, [2] * num_stages, stage_depths, gws, mult))
+    return out if se_ratio is None else [t + (se_ratio,) for t in out]
 
 
 class _ConvBN(nn.Sequential):
@@ -68,37 +74,43 @@ class _ConvBN(nn.Sequential):
 
 
 class BottleneckTransform(nn.Sequential):
-    def __init__(self, width_in, width_out, stride, group_width, bottleneck_multiplier):
+    def __init__(self, width_in, width_out, stride, group_width, bottleneck_multiplier, se_ratio=None):
         w_b = int(round(width_out * bottleneck_multiplier))
         layers = OrderedDict()
         layers["a"] = _ConvBN(width_in, w_b, 1)
         layers["b"] = _ConvBN(w_b, w_b, 3, stride=stride, groups=w_b // group_width)
+        if se_ratio:
+            layers["se"] = SqueezeExcitation(w_b, int(round(se_ratio * width_in)), activation="relu")
         layers["c"] = _ConvBN(w_b, width_out, 1, act=False)
         super().__init__(layers)
 
 
 class ResBottleneckBlock(nn.Module):
-    def __init__(self, width_in, width_out, stride, group_width=1, bottleneck_multiplier=1.0):
+    def __init__(self, width_in, width_out, stride, group_width=1, bottleneck_multiplier=1.0, se_ratio=None):
         super().__init__()
         self.proj = None
         if width_in != width_out or stride != 1:
             self.proj = _ConvBN(width_in, width_out, 1, stride=stride, act=False)
-        self.f = BottleneckTransform(width_in, width_out, stride, group_width, bottleneck_multiplier)
+        self.f = BottleneckTransform(width_in, width_out, stride, group_width, bottleneck_multiplier, se_ratio)
+        self.has_se = bool(se_ratio)
         self.activation = ReLU(inplace=True)
 
     def forward(self, x):
         identity = self.proj(x, defer=True) if self.proj is not None else x      # applied inside f.c's BN pass
         h = self.f.b(self.f.a(x))
+        if self.has_se:
+            h = self.f.se(h)
         return self.f.c(h, residual=identity, relu=True)          # BN + identity + ReLU in one pass
 
 
 class AnyStage(nn.Sequential):
-    def __init__(self, width_in, width_out, stride, depth, group_width, bottleneck_multiplier, stage_index):
+    def __init__(self, width_in, width_out, stride, depth, group_width, bottleneck_multiplier, stage_index,
+                 se_ratio=None):
         super().__init__()
         for i in range(depth):
             self.add_module("block%d-%d" % (stage_index, i),
                             ResBottleneckBlock(width_in if i == 0 else width_out, width_out, stride if i == 0 else 1,
-                                               group_width, bottleneck_multiplier))
+                                               group_width, bottleneck_multiplier, se_ratio))
 
 
 class RegNet(_ImageNetCNN):
@@ -108,8 +120,9 @@ class RegNet(_ImageNetCNN):
         self.stem[0].needs_input_grad = False
         width = stem_width
         blocks = []
-        for i, (w_out, stride, depth, gw, mult) in enumerate(params):
-            blocks.append(("block%d" % (i + 1), AnyStage(width, w_out, stride, depth, gw, mult, i + 1)))
+        for i, (w_out, stride, depth, gw, mult, *se) in enumerate(params):
+            blocks.append(("block%d" % (i + 1), AnyStage(width, w_out, stride, depth, gw, mult, i + 1,
+                                                         se[0] if se else None)))
             width = w_out
         self.trunk_output = nn.Sequential(OrderedDict(blocks))
         self.avgpool = AdaptiveAvgPool2d((1, 1))
@@ -158,3 +171,35 @@ def regnet_x_16gf(**kw):
 
 def regnet_x_32gf(**kw):
     return RegNet(block_params(depth=23, w_0=320, w_a=69.86, w_m=2.0, group_width=168), **kw)
+
+
+def regnet_y_400mf(**kw):
+    return RegNet(block_params(depth=16, w_0=48, w_a=27.89, w_m=2.09, group_width=8, se_ratio=0.25), **kw)
+
+
+def regnet_y_800mf(**kw):
+    return RegNet(block_params(depth=14, w_0=56, w_a=38.84, w_m=2.4, group_width=16, se_ratio=0.25), **kw)
+
+
+def regnet_y_1_6gf(**kw):
+    return RegNet(block_params(depth=27, w_0=48, w_a=20.71, w_m=2.65, group_width=24, se_ratio=0.25), **kw)
+
+
+def regnet_y_3_2gf(**kw):
+    return RegNet(block_params(depth=21, w_0=80, w_a=42.63, w_m=2.66, group_width=24, se_ratio=0.25), **kw)
+
+
+def regnet_y_8gf(**kw):
+    return RegNet(block_params(depth=17, w_0=192, w_a=76.82, w_m=2.19, group_width=56, se_ratio=0.25), **kw)
+
+
+def regnet_y_16gf(**kw):
+    return RegNet(block_params(depth=18, w_0=200, w_a=106.23, w_m=2.48, group_width=112, se_ratio=0.25), **kw)
+
+
+def regnet_y_32gf(**kw):
+    return RegNet(block_params(depth=20, w_0=232, w_a=115.89, w_m=2.53, group_width=232, se_ratio=0.25), **kw)
+
+
+def regnet_y_128gf(**kw):
+    return RegNet(block_params(depth=27, w_0=456, w_a=160.83, w_m=2.52, group_width=264, se_ratio=0.25), **kw)

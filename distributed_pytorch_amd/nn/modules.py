@@ -109,6 +109,78 @@ class ReLU6(nn.Module):
         return torch.clamp(x, 0.0, 6.0)
 
 
+class _Act(nn.Module):
+    kind = ""
+
+    def __init__(self, inplace: bool = False):
+        super().__init__()
+
+    def forward(self, x):
+        return F.activation(x, self.kind)
+
+
+class Sigmoid(_Act):
+    kind = "sigmoid"
+
+
+class SiLU(_Act):
+    kind = "silu"
+
+
+class Hardsigmoid(_Act):
+    kind = "hardsigmoid"
+
+
+class Hardswish(_Act):
+    kind = "hardswish"
+
+
+class StochasticDepth(nn.Module):
+    """torchvision ``StochasticDepth(p, mode="row")`` (EfficientNet)."""
+
+    def __init__(self, p: float, mode: str = "row"):
+        super().__init__()
+        if mode != "row":
+            raise ValueError("only the per-sample ('row') mode is used by the zoo")
+        self.p, self.mode = p, mode
+
+    def forward(self, x):
+        return F.stochastic_depth(x, self.p, self.training)
+
+
+class SqueezeExcitation(nn.Module):
+    """torchvision ``SqueezeExcitation``: ``x * gate(fc2(act(fc1(mean_hw(x)))))`` with 1x1-conv shaped parameters
+    (``fc1.weight [S, C, 1, 1]`` ...) so checkpoints interchange.
+
+    The activation-sized work -- the H*W mean, the gate multiply and its backward (``dx`` and the per-(sample, channel)
+    reduction of ``dy * x`` in one pass) -- runs in HIP kernels; the excitation MLP is two ``[N, C] x [C, S]`` fp32
+    products on a tensor 1/(H*W) the size of the activation and goes to the BLAS library through ``torch.addmm``
+    (squeeze widths such as 12 or 26 do not fill an MFMA tile, and at N x C elements the layer is launch latency,
+    not math)."""
+
+    def __init__(self, input_channels: int, squeeze_channels: int, activation: str = "relu",
+                 scale_activation: str = "sigmoid"):
+        super().__init__()
+        self.avgpool = AdaptiveAvgPool2d(1)
+        self.fc1 = Conv2d(input_channels, squeeze_channels, 1)
+        self.fc2 = Conv2d(squeeze_channels, input_channels, 1)
+        self.activation = ReLU() if activation == "relu" else SiLU()
+        self.scale_activation = Sigmoid() if scale_activation == "sigmoid" else Hardsigmoid()
+        self._act, self._gate = activation, scale_activation
+
+    def gate(self, x: torch.Tensor) -> torch.Tensor:
+        n, c = x.shape[0], x.shape[-1]
+        p = F.adaptive_avg_pool2d(x, (1, 1)).reshape(n, c).float()
+        w1, w2 = self.fc1.weight.flatten(1).float(), self.fc2.weight.flatten(1).float()
+        h = torch.addmm(self.fc1.bias.float(), p, w1.t())
+        h = torch.relu(h) if self._act == "relu" else torch.nn.functional.silu(h)
+        s = torch.addmm(self.fc2.bias.float(), h, w2.t())
+        return torch.sigmoid(s) if self._gate == "sigmoid" else torch.nn.functional.hardsigmoid(s)
+
+    def forward(self, x):
+        return F.se_scale(x, self.gate(x))
+
+
 class MaxPool2d(nn.Module):
     def __init__(self, kernel_size, stride=None, padding=0, ceil_mode: bool = False):
         super().__init__()
@@ -199,8 +271,10 @@ def conv_bn_relu_maxpool(x, conv: Conv2d, bn: BatchNorm2d, pool: "MaxPool2d"):
                                 pool.ceil_mode, stats=stats, group=bn.process_group)
 
 
-def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False, defer: bool = False):
-    """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  ``defer=True`` (downsample branches, ``relu=False``): the
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False, defer: bool = False,
+                act: Optional[str] = None):
+    """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  ``act`` ("silu", "hardswish", ...): a smooth activation
+    instead of ReLU, applied by its own elementwise kernel after the (activation-free) BN pass.  ``defer=True`` (downsample branches, ``relu=False``): the
     result may only be used as the ``residual`` of the block's last ``conv_bn_act`` (see ``F.batch_norm``).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
     re-read for statistics.  ``skip=True`` -> ``(out, x_alias)`` (see ``F.conv2d``)."""
@@ -209,9 +283,13 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip
     alias = None
     if skip:
         out, alias = out
+    if act is not None:
+        relu = False
     if fuse:
         y, stats = out
         res = bn(y, relu=relu, residual=residual, stats=stats, defer=defer)
     else:
         res = bn(out, relu=relu, residual=residual, defer=defer)
+    if act is not None:
+        res = F.activation(res, act)
     return (res, alias) if skip else res

@@ -196,6 +196,46 @@ def add_relu(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return TF.relu(x + y)
 
 
+def add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Residual ``x + y`` without activation (EfficientNet / MobileNetV3 under stochastic depth)."""
+    if _on_gpu(x):
+        return _hip().add(x, y)
+    return x + y
+
+
+_CPU_ACTS = {"sigmoid": torch.sigmoid, "silu": TF.silu, "hardsigmoid": TF.hardsigmoid, "hardswish": TF.hardswish}
+
+
+def activation(x: torch.Tensor, kind: str) -> torch.Tensor:
+    """``sigmoid`` / ``silu`` / ``hardsigmoid`` / ``hardswish`` (EfficientNet, MobileNetV3, squeeze-excitation)."""
+    if kind not in _CPU_ACTS:
+        raise ValueError("unknown activation %r" % (kind,))
+    if _on_gpu(x):
+        return _hip().activation(x, kind)
+    return _CPU_ACTS[kind](x)
+
+
+def se_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """``x[n, h, w, c] * s[n, c]``: the squeeze-excitation gate.  ``s`` is fp32 ``[N, C]``."""
+    if _on_gpu(x):
+        return _hip().se_scale(x, s)
+    return x * s.to(x.dtype).view(s.shape[0], 1, 1, s.shape[1])
+
+
+def stochastic_depth(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """torchvision ``StochasticDepth(p, "row")``: drops the whole residual branch of a sample with probability
+    ``p`` and rescales the survivors by ``1 / (1 - p)``."""
+    if not training or p == 0.0:
+        return x
+    keep = 1.0 - p
+    noise = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device).bernoulli_(keep)
+    if keep > 0.0:
+        noise.div_(keep)
+    if _on_gpu(x):
+        return _hip().se_scale(x, noise.expand(x.shape[0], x.shape[-1]))
+    return x * noise.to(x.dtype).view(-1, 1, 1, 1)
+
+
 def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
     if not training or p == 0.0:
         return x

@@ -1244,6 +1244,91 @@ def add_relu(a, b):
     return _AddReluFn.apply(a, b)
 
 
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        y = torch.empty_like(a)
+        C().add_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _dt(a), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("add: operands must have the same shape and dtype")
+    return _AddFn.apply(a, b)
+
+
+ACT_CODES = {"sigmoid": 1, "silu": 2, "hardsigmoid": 3, "hardswish": 4}
+
+
+class _ActFn(torch.autograd.Function):
+    """Smooth activations of EfficientNet / MobileNetV3.  The input is saved and the slope recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, x, code):
+        x = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(x)
+        C().act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), code, _dt(x), _stream())
+        ctx.save_for_backward(x)
+        ctx.code = code
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dy)
+        C().act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dy.numel(), ctx.code, _dt(dy), _stream())
+        return dx, None
+
+
+def activation(x, kind: str):
+    return _ActFn.apply(x, ACT_CODES[kind])
+
+
+class _SEScaleFn(torch.autograd.Function):
+    """``y[n, h, w, c] = x[n, h, w, c] * s[n, c]`` -- the squeeze-excitation gate (and stochastic depth, where ``s``
+    needs no gradient).  Backward: one pass writes ``dx = dy * s`` and reduces ``ds = sum_hw dy * x``."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, H, W, Cc = x.shape
+        if s.shape != (NB, Cc):
+            raise ValueError("se_scale: scale must be [N, C]")
+        if Cc % _vec(x.dtype):
+            raise ValueError("se_scale: C must be a multiple of %d" % _vec(x.dtype))
+        s = _f32(s.detach()).contiguous()
+        y = torch.empty_like(x)
+        C().se_scale_fwd(x.data_ptr(), s.data_ptr(), y.data_ptr(), NB, H * W, Cc, _dt(x), _stream())
+        ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        NB, H, W, Cc = dy.shape
+        dx = torch.empty_like(dy)
+        if x is None:                               # the scale is a constant (stochastic depth)
+            C().se_scale_fwd(dy.data_ptr(), s.data_ptr(), dx.data_ptr(), NB, H * W, Cc, _dt(dy), _stream())
+            return dx, None
+        ds = torch.empty((NB, Cc), dtype=torch.float32, device=dy.device)
+        C().se_scale_bwd(dy.data_ptr(), x.data_ptr(), s.data_ptr(), dx.data_ptr(), ds.data_ptr(), NB, H * W, Cc,
+                         _dt(dy), _stream())
+        return dx, ds
+
+
+def se_scale(x, s):
+    return _SEScaleFn.apply(x, s)
+
+
 _dropout_counters: Dict[int, torch.Tensor] = {}
 
 

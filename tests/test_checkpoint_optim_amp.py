@@ -18,7 +18,10 @@ def test_param_counts_and_torchvision_key_names():
             "squeezenet1_0": 1248424, "squeezenet1_1": 1235496, "densenet121": 7978856, "densenet169": 14149480,
             "resnext50_32x4d": 25028904, "wide_resnet50_2": 68883240,
             "mobilenet_v2": 3504872, "mnasnet1_0": 4383312, "mnasnet0_5": 2218512,
-            "googlenet": 6624904, "regnet_x_400mf": 5495976, "regnet_x_1_6gf": 9190136, "regnet_x_8gf": 39572648}
+            "googlenet": 6624904, "regnet_x_400mf": 5495976, "regnet_x_1_6gf": 9190136, "regnet_x_8gf": 39572648,
+            "regnet_y_400mf": 4344144, "regnet_y_1_6gf": 11202430, "mobilenet_v3_large": 5483032,
+            "mobilenet_v3_small": 2542856, "efficientnet_b0": 5288548, "efficientnet_b3": 12233232,
+            "efficientnet_v2_s": 21458488}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch
@@ -44,6 +47,18 @@ def test_param_counts_and_torchvision_key_names():
     rg = models.create_model("regnet_x_400mf").state_dict()
     assert rg["trunk_output.block3.block3-0.f.b.0.weight"].shape == (160, 16, 3, 3) and "stem.1.running_mean" in rg \
         and "trunk_output.block2.block2-0.proj.0.weight" in rg
+    ry = models.create_model("regnet_y_400mf").state_dict()
+    assert ry["trunk_output.block2.block2-0.f.se.fc1.weight"].shape == (12, 104, 1, 1) \
+        and ry["trunk_output.block2.block2-0.f.se.fc2.bias"].shape == (104,)
+    m3 = models.create_model("mobilenet_v3_large").state_dict()
+    assert m3["features.4.block.2.fc1.weight"].shape == (24, 72, 1, 1) and m3["features.4.block.1.0.weight"].shape \
+        == (72, 1, 5, 5) and m3["classifier.0.weight"].shape == (1280, 960) and "features.16.1.running_var" in m3
+    ef = models.create_model("efficientnet_b0").state_dict()
+    assert ef["features.2.0.block.2.fc1.weight"].shape == (4, 96, 1, 1) and ef["features.8.0.weight"].shape \
+        == (1280, 320, 1, 1) and ef["features.1.0.block.0.0.weight"].shape == (32, 1, 3, 3)
+    e2 = models.create_model("efficientnet_v2_s").state_dict()
+    assert e2["features.1.0.block.0.0.weight"].shape == (24, 24, 3, 3) and e2["features.2.0.block.1.0.weight"].shape \
+        == (48, 96, 1, 1) and e2["features.4.0.block.2.fc2.weight"].shape == (256, 16, 1, 1)
     sq = models.create_model("squeezenet1_1").state_dict()
     assert sq["features.3.squeeze.weight"].shape == (16, 64, 1, 1) and sq["classifier.1.weight"].shape == (1000, 512, 1, 1)
     al = models.create_model("alexnet").state_dict()

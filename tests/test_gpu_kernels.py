@@ -279,6 +279,59 @@ def test_relu_add_dropout_normalize():
     assert torch.equal(h[..., :3], xf.permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_smooth_activations_se_gate_and_stochastic_depth(dtype):
+    """act_fwd / act_bwd (sigmoid, SiLU, hard-sigmoid, hard-swish), the squeeze-excitation gate (dx and the
+    per-(sample, channel) reduction in one pass), plain residual add and row-mode stochastic depth against fp32
+    PyTorch references."""
+    import torch.nn.functional as TF
+
+    torch.manual_seed(21)
+    ref_act = {"sigmoid": torch.sigmoid, "silu": TF.silu, "hardsigmoid": TF.hardsigmoid, "hardswish": TF.hardswish}
+    for shape in ((3, 5, 7, 40), (2, 1283)):                   # second: scalar tail path (1283 % 8 != 0)
+        x0 = (torch.randn(*shape, device=DEV) * 3).to(dtype)
+        g0 = torch.randn(*shape, device=DEV).to(dtype)
+        for kind, fn in ref_act.items():
+            x = x0.clone().requires_grad_(True)
+            y = F.activation(x, kind)
+            y.backward(g0)
+            xr = x0.float().clone().requires_grad_(True)
+            yr = fn(xr)
+            yr.backward(g0.float())
+            _close(y, yr, dtype)
+            _close(x.grad, xr.grad, dtype)
+    for (NB, H, W, Cc) in ((3, 7, 7, 48), (2, 9, 5, 136), (5, 1, 1, 8)):
+        x0 = torch.randn(NB, H, W, Cc, device=DEV).to(dtype)
+        s0 = torch.rand(NB, Cc, device=DEV)
+        g0 = torch.randn(NB, H, W, Cc, device=DEV).to(dtype)
+        x, s = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        y = F.se_scale(x, s)
+        y.backward(g0)
+        xr, sr = x0.float().clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        yr = xr * sr.view(NB, 1, 1, Cc)
+        yr.backward(g0.float())
+        _close(y, yr, dtype)
+        _close(x.grad, xr.grad, dtype)
+        assert s.grad.dtype == torch.float32
+        _close(s.grad, sr.grad, dtype)
+    a = torch.randn(4, 3, 3, 24, device=DEV).to(dtype).requires_grad_(True)
+    b = torch.randn(4, 3, 3, 24, device=DEV).to(dtype).requires_grad_(True)
+    y = F.add(a, b)
+    y.backward(torch.ones_like(y))
+    _close(y, a.detach().float() + b.detach().float(), dtype)
+    assert torch.equal(a.grad, torch.ones_like(a)) and torch.equal(b.grad, a.grad)
+    x = torch.ones(512, 2, 2, 8, device=DEV, dtype=dtype).requires_grad_(True)
+    y = F.stochastic_depth(x, 0.25, True)
+    y.sum().backward()
+    per = y.detach().float().reshape(512, -1)
+    assert bool((per.min(1).values == per.max(1).values).all())            # whole samples are kept or dropped
+    vals = set(round(v, 3) for v in per[:, 0].unique().tolist())
+    assert vals <= {0.0, round(1 / 0.75, 3)} or dtype != torch.float32
+    assert 0.15 < (per[:, 0] == 0).float().mean().item() < 0.35
+    assert torch.equal(x.grad.float().reshape(512, -1)[:, 0], per[:, 0])   # same mask scales the gradient
+    assert F.stochastic_depth(x, 0.25, False) is x
+
+
 @pytest.mark.parametrize("lp", [None, torch.bfloat16])
 def test_fused_sgd_matches_torch(lp):
     from distributed_pytorch_amd.optim import FusedSGD

@@ -23,15 +23,18 @@ def _run(model, x, t):
 @pytest.mark.parametrize("arch,size,tol", [("resnet18", 64, 2e-3), ("resnet50", 128, 3e-3), ("alexnet", 224, 2e-3),
                                            ("vgg11_bn", 128, 3e-3), ("squeezenet1_1", 127, 2e-3), ("squeezenet1_0", 96, 2e-3),
                                            ("densenet121", 64, 3e-3), ("resnext50_32x4d", 128, 4e-3), ("mobilenet_v2", 96, 4e-3), ("mnasnet0_5", 96, 4e-3),
-                                           ("googlenet", 96, 3e-3), ("regnet_x_400mf", 96, 4e-3)])
+                                           ("googlenet", 96, 3e-3), ("regnet_x_400mf", 96, 4e-3),
+                                           ("regnet_y_400mf", 96, 4e-3), ("mobilenet_v3_small", 96, 4e-3),
+                                           ("mobilenet_v3_large", 64, 4e-3), ("efficientnet_b0", 64, 4e-3),
+                                           ("efficientnet_v2_s", 64, 4e-3)])
 def test_fp32_model_matches_cpu_reference(arch, size, tol):
     from distributed_pytorch_amd import amp, models
 
     amp.state().reset()
     torch.manual_seed(0)
     cpu = models.create_model(arch, num_classes=1000)
-    for m in cpu.modules():                      # no dropout noise in the comparison
-        if m.__class__.__name__ == "Dropout":
+    for m in cpu.modules():                      # no dropout / stochastic-depth noise in the comparison
+        if m.__class__.__name__ in ("Dropout", "StochasticDepth"):
             m.p = 0.0
     gpu = copy.deepcopy(cpu).cuda()
     x = torch.randn(4, 3, size, size)
