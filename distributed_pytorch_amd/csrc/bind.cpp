@@ -222,6 +222,11 @@ PYBIND11_MODULE(_C, m) {
                           uintptr_t s) {
     avgpool_fwd_launch(ptr<const void>(x), ptr<void>(y), NB, IH, IW, C, OH, OW, dtype, st(s));
   });
+  m.def("avgpool_win", [](uintptr_t src, uintptr_t dst, int backward, int NB, int IH, int IW, int C, int OH, int OW,
+                          int kh, int kw, int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
+    avgpool_win_launch(ptr<const void>(src), ptr<void>(dst), backward, NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw,
+                       dtype, st(s));
+  });
   m.def("avgpool_bwd", [](uintptr_t dy, uintptr_t dx, int NB, int IH, int IW, int C, int OH, int OW, int dtype,
                           uintptr_t s) {
     avgpool_bwd_launch(ptr<const void>(dy), ptr<void>(dx), NB, IH, IW, C, OH, OW, dtype, st(s));

@@ -152,6 +152,9 @@ void bn_relu_maxpool_bwd_apply_launch(const uint8_t* idx, const void* dyp, const
                                       int kh, int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, int OH, int OW,
                         int dtype, hipStream_t s);
+// fixed window with zero padding counted in the divisor; backward != 0: src = dy, dst = dx
+void avgpool_win_launch(const void* src, void* dst, int backward, int NB, int IH, int IW, int C, int OH, int OW, int kh,
+                        int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 void avgpool_bwd_launch(const void* dy, void* dx, int NB, int IH, int IW, int C, int OH, int OW,
                         int dtype, hipStream_t s);
 

@@ -368,6 +368,75 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// Fixed-window average pooling with zero padding counted in the divisor (torch's count_include_pad=True; Inception's
+// 3x3 stride-1 pad-1 branch pool).  Windows overlap, so backward gathers: input pixel (iy, ix) sums dy over the output
+// positions whose window covers it -- no atomics, fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_win_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolGeom g,
+                                                              long total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cc = g.C / VEC;
+  const float inv = 1.f / (float)(g.kh * g.kw);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cc);
+    long pix = i / cc;
+    const int ox = (int)(pix % g.OW); pix /= g.OW;
+    const int oy = (int)(pix % g.OH);
+    const int n = (int)(pix / g.OH);
+    const int y0 = max(oy * g.sh - g.ph, 0), y1 = min(oy * g.sh - g.ph + g.kh, g.IH);
+    const int x0 = max(ox * g.sw - g.pw, 0), x1 = min(ox * g.sw - g.pw + g.kw, g.IW);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        Vec16<T> v;
+        v.load(x + (((size_t)n * g.IH + yy) * g.IW + xx) * g.C + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += v.get(j);
+      }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, acc[j] * inv);
+    o.store(y + i * VEC);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_win_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, PoolGeom g,
+                                                              long total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int cc = g.C / VEC;
+  const float inv = 1.f / (float)(g.kh * g.kw);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cc);
+    long pix = i / cc;
+    const int ix = (int)(pix % g.IW); pix /= g.IW;
+    const int iy = (int)(pix % g.IH);
+    const int n = (int)(pix / g.IH);
+    // outputs o with o*s - p <= i < o*s - p + k
+    const int ty = iy + g.ph, tx = ix + g.pw;
+    const int oy0 = max((ty - g.kh + g.sh) / g.sh, 0), oy1 = min(ty / g.sh, g.OH - 1);
+    const int ox0 = max((tx - g.kw + g.sw) / g.sw, 0), ox1 = min(tx / g.sw, g.OW - 1);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy)
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        Vec16<T> d;
+        d.load(dy + (((size_t)n * g.OH + oy) * g.OW + ox) * g.C + c * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += d.get(j);
+      }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, acc[j] * inv);
+    o.store(dx + i * VEC);
+  }
+}
+
 inline int grid_for(long n) {
   long b = (n + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -511,6 +580,26 @@ void avgpool_bwd_launch(const void* dy, void* dx, int NB, int IH, int IW, int C,
   if (total <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
                                                (const T*)dy, (T*)dx, g, total));
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void avgpool_win_launch(const void* src, void* dst, int backward, int NB, int IH, int IW, int C, int OH, int OW, int kh,
+                        int kw, int sh, int sw, int ph, int pw, int dtype, hipStream_t s) {
+  check_c(C, dtype);
+  if (kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || 2 * ph > kh || 2 * pw > kw)
+    throw std::invalid_argument("avgpool_win: bad window");
+  if (OH != (IH + 2 * ph - kh) / sh + 1 || OW != (IW + 2 * pw - kw) / sw + 1)
+    throw std::invalid_argument("avgpool_win: output extent does not match the window");
+  PoolGeom g{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
+  const long total = (long)NB * (backward ? IH * IW : OH * OW) * (C / (dtype == kF32 ? 4 : 8));
+  if (total <= 0) return;
+  if (backward) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_win_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)src, (T*)dst, g, total));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_win_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)src, (T*)dst, g, total));
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 

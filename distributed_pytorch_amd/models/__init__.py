@@ -9,13 +9,14 @@ from . import alexnet_vgg as _av
 from . import densenet as _dn
 from . import efficientnet as _ef
 from . import googlenet as _gn
+from . import inception as _in
 from . import mobilenet as _mb
 from . import regnet as _rg
 from . import resnet as _rn
 from . import squeezenet as _sq
 
 _REGISTRY: Dict[str, Callable] = {}
-for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef):
+for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in):
     for _name in dir(_mod):
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("_") and callable(_fn) \

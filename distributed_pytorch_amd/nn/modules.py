@@ -191,12 +191,12 @@ class MaxPool2d(nn.Module):
 
 
 class AvgPool2d(nn.Module):
-    def __init__(self, kernel_size, stride=None):
+    def __init__(self, kernel_size, stride=None, padding=0):
         super().__init__()
-        self.kernel_size, self.stride = kernel_size, stride
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
 
     def forward(self, x):
-        return F.avg_pool2d(x, self.kernel_size, self.stride)
+        return F.avg_pool2d(x, self.kernel_size, self.stride, self.padding)
 
 
 class AdaptiveAvgPool2d(nn.Module):

@@ -155,15 +155,16 @@ def max_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, ceil_mode: 
     return TF.max_pool2d(x.permute(0, 3, 1, 2), k, s, p, ceil_mode=ceil_mode).permute(0, 2, 3, 1).contiguous()
 
 
-def avg_pool2d(x: torch.Tensor, kernel_size, stride=None) -> torch.Tensor:
-    """Non-overlapping average pooling (DenseNet transitions: 2x2 stride 2 on even extents) -- on the GPU this
-    is the adaptive average-pool kernel with the output extent H/k."""
-    k, s = _pair(kernel_size), _pair(stride if stride is not None else kernel_size)
-    if k != s or x.shape[1] % k[0] or x.shape[2] % k[1]:
-        if _on_gpu(x):
-            raise NotImplementedError("avg_pool2d on the GPU supports kernel == stride dividing the input extent")
-        return TF.avg_pool2d(x.permute(0, 3, 1, 2), k, s).permute(0, 2, 3, 1).contiguous()
-    return adaptive_avg_pool2d(x, (x.shape[1] // k[0], x.shape[2] // k[1]))
+def avg_pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0) -> torch.Tensor:
+    """Average pooling (floor mode, padding counted in the divisor like torch's default).  Non-overlapping windows
+    that tile the input (DenseNet transitions: 2x2 stride 2) run on the adaptive average-pool kernel; everything
+    else (Inception's 3x3 stride-1 pad-1 branch pool, its 5x5 stride-3 auxiliary pool) on the fixed-window kernel."""
+    k, s, p = _pair(kernel_size), _pair(stride if stride is not None else kernel_size), _pair(padding)
+    if k == s and p == (0, 0) and x.shape[1] % k[0] == 0 and x.shape[2] % k[1] == 0:
+        return adaptive_avg_pool2d(x, (x.shape[1] // k[0], x.shape[2] // k[1]))
+    if _on_gpu(x):
+        return _hip().avg_pool2d_window(x, k, s, p)
+    return TF.avg_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
 
 
 def cat_channels(xs) -> torch.Tensor:

@@ -1193,6 +1193,34 @@ class _AvgPoolFn(torch.autograd.Function):
         return dx, None
 
 
+class _AvgPoolWinFn(torch.autograd.Function):
+    """Fixed-window average pooling, overlapping windows and zero padding allowed (count_include_pad=True)."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, IH, IW, Cc = x.shape
+        OH, OW = (IH + 2 * p[0] - k[0]) // s[0] + 1, (IW + 2 * p[1] - k[1]) // s[1] + 1
+        y = torch.empty((NB, OH, OW, Cc), dtype=x.dtype, device=x.device)
+        C().avgpool_win(x.data_ptr(), y.data_ptr(), 0, NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1],
+                        _dt(x), _stream())
+        ctx.cfg = (x.shape, (OH, OW), k, s, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (NB, IH, IW, Cc), (OH, OW), k, s, p = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty((NB, IH, IW, Cc), dtype=dy.dtype, device=dy.device)
+        C().avgpool_win(dy.data_ptr(), dx.data_ptr(), 1, NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1],
+                        _dt(dy), _stream())
+        return dx, None, None, None
+
+
+def avg_pool2d_window(x, k, s, p):
+    return _AvgPoolWinFn.apply(x, tuple(k), tuple(s), tuple(p))
+
+
 def adaptive_avg_pool2d(x, o):
     if x.shape[1] == o[0] and x.shape[2] == o[1]:
         return x                      # identity at 224x224 for AlexNet (6x6) / VGG (7x7)

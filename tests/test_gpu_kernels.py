@@ -36,6 +36,11 @@ CONV_CASES = [
     (2, 67, 67, 3, 64, 11, 4, 2),       # AlexNet conv1
     (2, 7, 7, 512, 512, 3, 1, 1),
     (5, 7, 7, 256, 1024, 1, 1, 0),
+    (2, 17, 17, 128, 192, (1, 7), 1, (0, 3)),     # Inception v3 factorised filters
+    (2, 17, 17, 160, 160, (7, 1), 1, (3, 0)),
+    (2, 8, 8, 384, 384, (1, 3), 1, (0, 1)),       # one filter row (filter-row kernel)
+    (2, 8, 8, 448, 384, (3, 1), 1, (1, 0)),
+    (2, 17, 15, 64, 96, (3, 5), (2, 1), (1, 2)),  # everything different per axis
 ]
 
 
@@ -44,8 +49,9 @@ CONV_CASES = [
 @pytest.mark.parametrize("bias_relu", [False, True])
 def test_conv_fwd_bwd(case, dtype, bias_relu):
     N, H, W, Cin, Cout, k, s, p = case
-    if bias_relu and k not in (3, 5, 11):
+    if bias_relu and k not in (3, 5, 11, (1, 3), (3, 5)):
         pytest.skip("bias/relu epilogue covered on a subset")
+    kh, kw = (k, k) if isinstance(k, int) else k
     torch.manual_seed(0)
     vec = 4 if dtype == torch.float32 else 8
     Cx = Cin if Cin % vec == 0 else 8
@@ -53,7 +59,7 @@ def test_conv_fwd_bwd(case, dtype, bias_relu):
     xp = torch.zeros(N, H, W, Cx, device=DEV)
     xp[..., :Cin] = x
     xq = xp.to(dtype).requires_grad_(Cx == Cin)
-    w = (torch.randn(Cout, Cin, k, k, device=DEV) / (Cin * k * k) ** 0.5).contiguous(
+    w = (torch.randn(Cout, Cin, kh, kw, device=DEV) / (Cin * kh * kw) ** 0.5).contiguous(
         memory_format=torch.channels_last).requires_grad_(True)
     b = torch.randn(Cout, device=DEV).requires_grad_(True) if bias_relu else None
     y = F.conv2d(xq, w, b, s, p, relu=bias_relu, needs_input_grad=(Cx == Cin))
@@ -72,7 +78,6 @@ def test_conv_fwd_bwd(case, dtype, bias_relu):
         assert flips < 1e-3, "relu mask mismatch fraction %g" % flips
         yr = yr * mask
     yr.backward(gy.float().permute(0, 3, 1, 2))
-    K = Cin * k * k
     _close(y.permute(0, 3, 1, 2), yr, dtype, what="fprop")
     if Cx == Cin:
         _close(xq.grad.permute(0, 3, 1, 2), xr.grad, dtype, scale=1.0, what="dgrad")
@@ -205,6 +210,26 @@ def test_avg_pool(dtype, H, o):
     xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
     yr = TF.adaptive_avg_pool2d(xr, o)
     yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype)
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W,k,s,p", [(17, 17, 3, 1, 1), (17, 17, 5, 3, 0), (9, 12, (3, 2), (2, 1), (1, 1)),
+                                       (7, 7, 2, 2, 0), (35, 35, 3, 1, 1)])
+def test_avg_pool_fixed_window(dtype, H, W, k, s, p):
+    """Overlapping / padded windows (Inception branch pools, the auxiliary head's 5x5 stride 3; padding counts in the
+    divisor) and a floor-mode window that does not tile the input (7 / 2)."""
+    torch.manual_seed(5)
+    x = torch.randn(2, H, W, 40, device=DEV).to(dtype).requires_grad_(True)
+    y = F.avg_pool2d(x, k, s, p)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+    # reference on the CPU: ATen's GPU avg_pool2d backward returns a shifted gradient for a padded window on a
+    # channels_last-strided input (seen on ROCm 7 / torch 2.10: corner 1/9 instead of 4/9 for 3x3 s1 p1)
+    xr = x.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yr = TF.avg_pool2d(xr, k, s, p)
+    yr.backward(gy.float().cpu().permute(0, 3, 1, 2).contiguous())
     _close(y.permute(0, 3, 1, 2), yr, dtype)
     _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype)
 
