@@ -263,6 +263,19 @@ PYBIND11_MODULE(_C, m) {
   m.def("relu_bwd", [](uintptr_t y, uintptr_t dy, uintptr_t dx, long n, int dtype, uintptr_t s) {
     relu_bwd_launch(ptr<const void>(y), ptr<const void>(dy), ptr<void>(dx), n, dtype, st(s));
   });
+  m.def("ln_partial_rows", &ln_partial_rows);
+  m.def("ln_fwd", [](uintptr_t x, uintptr_t w, uintptr_t b, uintptr_t y, uintptr_t mean, uintptr_t rstd, long rows, int C,
+                     float eps, int dtype, uintptr_t s) {
+    ln_fwd_launch(ptr<const void>(x), ptr<const float>(w), ptr<const float>(b), ptr<void>(y), ptr<float>(mean),
+                  ptr<float>(rstd), rows, C, eps, dtype, st(s));
+  });
+  m.def("ln_bwd", [](uintptr_t dy, uintptr_t x, uintptr_t w, uintptr_t mean, uintptr_t rstd, uintptr_t dx,
+                     uintptr_t partial, uintptr_t dgamma, uintptr_t dbeta, float beta_w, float beta_b, long rows, int C,
+                     int dtype, uintptr_t s) {
+    ln_bwd_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const float>(w), ptr<const float>(mean),
+                  ptr<const float>(rstd), ptr<void>(dx), ptr<float>(partial), ptr<float>(dgamma), ptr<float>(dbeta),
+                  beta_w, beta_b, rows, C, dtype, st(s));
+  });
   m.def("add_fwd", [](uintptr_t a, uintptr_t b, uintptr_t y, long n, int dtype, uintptr_t s) {
     add_fwd_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(y), n, dtype, st(s));
   });

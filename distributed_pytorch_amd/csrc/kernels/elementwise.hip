@@ -146,13 +146,15 @@ void ew_launch(const void* a, const void* b, void* y, long n, hipStream_t s) {
 
 
 // ---- smooth activations (EfficientNet / MobileNetV3 / squeeze-excitation gates) -------------------------------
-// act: 1 sigmoid, 2 SiLU (x * sigmoid(x)), 3 hard-sigmoid (relu6(x + 3) / 6), 4 hard-swish (x * hard-sigmoid(x)).
+// act: 1 sigmoid, 2 SiLU (x * sigmoid(x)), 3 hard-sigmoid (relu6(x + 3) / 6), 4 hard-swish (x * hard-sigmoid(x)),
+// 5 GELU (exact, erf).
 // Backward recomputes the derivative from the saved INPUT, so no activation-sized mask / output is kept.
 __device__ __forceinline__ float act_value(int act, float x) {
   switch (act) {
     case 1: return 1.f / (1.f + __expf(-x));
     case 2: return x / (1.f + __expf(-x));
     case 3: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    case 5: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
     default: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
   }
 }
@@ -161,6 +163,7 @@ __device__ __forceinline__ float act_slope(int act, float x) {
     case 1: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
     case 2: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
     case 3: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
+    case 5: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
     default: return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f));   // ATen's convention at +-3
   }
 }
@@ -415,12 +418,12 @@ void add_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hi
 }
 
 void act_fwd_launch(const void* x, void* y, long n, int act, int dtype, hipStream_t s) {
-  if (act < 1 || act > 4) throw std::invalid_argument("act: unknown activation code");
+  if (act < 1 || act > 5) throw std::invalid_argument("act: unknown activation code");
   if (n <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, (act_launch_t<T, false>(x, nullptr, y, n, act, s)));
 }
 void act_bwd_launch(const void* x, const void* dy, void* dx, long n, int act, int dtype, hipStream_t s) {
-  if (act < 1 || act > 4) throw std::invalid_argument("act: unknown activation code");
+  if (act < 1 || act > 5) throw std::invalid_argument("act: unknown activation code");
   if (n <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, (act_launch_t<T, true>(x, dy, dx, n, act, s)));
 }

@@ -176,8 +176,15 @@ void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad
 void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
 void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
+// LayerNorm over the last axis of [rows][C]; backward folds dgamma / dbeta from ln_partial_rows() partial rows
+int ln_partial_rows(long rows, int C, int dtype);
+void ln_fwd_launch(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, long rows, int C,
+                   float eps, int dtype, hipStream_t s);
+void ln_bwd_launch(const void* dy, const void* x, const float* w, const float* mean, const float* rstd, void* dx,
+                   float* partial, float* dgamma, float* dbeta, float beta_w, float beta_b, long rows, int C, int dtype,
+                   hipStream_t s);
 void add_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
-// act: 1 sigmoid, 2 SiLU, 3 hard-sigmoid, 4 hard-swish; backward recomputes the slope from the input x
+// act: 1 sigmoid, 2 SiLU, 3 hard-sigmoid, 4 hard-swish, 5 GELU (erf); backward recomputes the slope from the input x
 void act_fwd_launch(const void* x, void* y, long n, int act, int dtype, hipStream_t s);
 void act_bwd_launch(const void* x, const void* dy, void* dx, long n, int act, int dtype, hipStream_t s);
 // y[n][p][c] = x[n][p][c] * sc[n][c] (squeeze-excitation gate / stochastic depth); backward: dx and ds = sum_p dy * x

@@ -6,6 +6,7 @@ from __future__ import annotations
 from typing import Callable, Dict, List
 
 from . import alexnet_vgg as _av
+from . import convnext as _cx
 from . import densenet as _dn
 from . import efficientnet as _ef
 from . import googlenet as _gn
@@ -16,7 +17,7 @@ from . import resnet as _rn
 from . import squeezenet as _sq
 
 _REGISTRY: Dict[str, Callable] = {}
-for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in):
+for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in, _cx):
     for _name in dir(_mod):
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("_") and callable(_fn) \

@@ -135,6 +135,30 @@ class Hardswish(_Act):
     kind = "hardswish"
 
 
+class GELU(_Act):
+    kind = "gelu"
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm over the channel (last) axis of NHWC activations; stands for both ``nn.LayerNorm(C)`` and
+    torchvision's ``LayerNorm2d(C)`` (same parameters: ``weight``, ``bias`` of shape ``[C]``)."""
+
+    def __init__(self, normalized_shape: int, eps: float = 1e-5):
+        super().__init__()
+        self.normalized_shape, self.eps = (int(normalized_shape),), eps
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+
+    def forward(self, x):
+        return F.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def extra_repr(self) -> str:
+        return "{}, eps={}".format(self.normalized_shape, self.eps)
+
+
+LayerNorm2d = LayerNorm
+
+
 class StochasticDepth(nn.Module):
     """torchvision ``StochasticDepth(p, mode="row")`` (EfficientNet)."""
 

@@ -204,16 +204,25 @@ def add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return x + y
 
 
-_CPU_ACTS = {"sigmoid": torch.sigmoid, "silu": TF.silu, "hardsigmoid": TF.hardsigmoid, "hardswish": TF.hardswish}
+_CPU_ACTS = {"sigmoid": torch.sigmoid, "silu": TF.silu, "hardsigmoid": TF.hardsigmoid, "hardswish": TF.hardswish,
+             "gelu": TF.gelu}
 
 
 def activation(x: torch.Tensor, kind: str) -> torch.Tensor:
-    """``sigmoid`` / ``silu`` / ``hardsigmoid`` / ``hardswish`` (EfficientNet, MobileNetV3, squeeze-excitation)."""
+    """``sigmoid`` / ``silu`` / ``hardsigmoid`` / ``hardswish`` / ``gelu`` (erf form): EfficientNet, MobileNetV3,
+    squeeze-excitation, ConvNeXt."""
     if kind not in _CPU_ACTS:
         raise ValueError("unknown activation %r" % (kind,))
     if _on_gpu(x):
         return _hip().activation(x, kind)
     return _CPU_ACTS[kind](x)
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm over the last (channel) axis -- in NHWC torchvision's ``LayerNorm2d`` and ``nn.LayerNorm`` coincide."""
+    if _on_gpu(x):
+        return _hip().layer_norm(x, weight, bias, eps)
+    return TF.layer_norm(x.float(), (x.shape[-1],), weight.float(), bias.float(), eps).to(x.dtype)
 
 
 def se_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:

@@ -1292,7 +1292,7 @@ def add(a, b):
     return _AddFn.apply(a, b)
 
 
-ACT_CODES = {"sigmoid": 1, "silu": 2, "hardsigmoid": 3, "hardswish": 4}
+ACT_CODES = {"sigmoid": 1, "silu": 2, "hardsigmoid": 3, "hardswish": 4, "gelu": 5}
 
 
 class _ActFn(torch.autograd.Function):
@@ -1318,6 +1318,51 @@ class _ActFn(torch.autograd.Function):
 
 def activation(x, kind: str):
     return _ActFn.apply(x, ACT_CODES[kind])
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last axis (ConvNeXt).  fp32 statistics, one read + one write forward; backward writes dx and
+    folds dgamma / dbeta from one partial row per workgroup (fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        if weight.shape != (Cc,) or bias.shape != (Cc,):
+            raise ValueError("layer_norm: weight / bias must be [C]")
+        if Cc % _vec(x.dtype):
+            raise ValueError("layer_norm: C must be a multiple of %d" % _vec(x.dtype))
+        w, b = _f32(weight.detach()).contiguous(), _f32(bias.detach()).contiguous()
+        y = torch.empty_like(x)
+        stat = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+        C().ln_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stat[0].data_ptr(), stat[1].data_ptr(), rows,
+                   Cc, float(eps), _dt(x), _stream())
+        ctx.save_for_backward(x, w, stat)
+        ctx.refs = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, stat = ctx.saved_tensors
+        weight, bias = ctx.refs
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dx = torch.empty_like(x)
+        nparts = C().ln_partial_rows(rows, Cc, _dt(x))
+        partial = torch.empty((nparts, 2, Cc), dtype=torch.float32, device=x.device)
+        dwb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        C().ln_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), stat[0].data_ptr(), stat[1].data_ptr(), dx.data_ptr(),
+                   partial.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), 0.0, 0.0, rows, Cc, _dt(x), _stream())
+        dw = _deliver(weight, dwb[0].to(weight.dtype)) if ctx.needs_input_grad[1] else None
+        db = _deliver(bias, dwb[1].to(bias.dtype)) if ctx.needs_input_grad[2] else None
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None
+
+
+def layer_norm(x, weight, bias, eps):
+    grad_sink.note_use(weight, bias)
+    return _LayerNormFn.apply(x, weight, bias, float(eps))
 
 
 class _SEScaleFn(torch.autograd.Function):

@@ -21,7 +21,7 @@ def test_param_counts_and_torchvision_key_names():
             "googlenet": 6624904, "regnet_x_400mf": 5495976, "regnet_x_1_6gf": 9190136, "regnet_x_8gf": 39572648,
             "regnet_y_400mf": 4344144, "regnet_y_1_6gf": 11202430, "mobilenet_v3_large": 5483032,
             "mobilenet_v3_small": 2542856, "efficientnet_b0": 5288548, "efficientnet_b3": 12233232,
-            "efficientnet_v2_s": 21458488, "inception_v3": 23834568}
+            "efficientnet_v2_s": 21458488, "inception_v3": 23834568, "convnext_tiny": 28589128}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch
@@ -65,6 +65,10 @@ def test_param_counts_and_torchvision_key_names():
     assert iv["Mixed_6b.branch7x7_2.conv.weight"].shape == (128, 128, 1, 7) and iv["AuxLogits.conv1.conv.weight"].shape \
         == (768, 128, 5, 5) and iv["Mixed_7c.branch3x3dbl_3b.conv.weight"].shape == (384, 384, 3, 1) \
         and "Conv2d_1a_3x3.bn.running_mean" in iv
+    cx = models.create_model("convnext_tiny").state_dict()
+    assert cx["features.1.0.block.0.weight"].shape == (96, 1, 7, 7) and cx["features.1.0.layer_scale"].shape == (96, 1, 1) \
+        and cx["features.1.0.block.3.weight"].shape == (384, 96) and cx["features.2.1.weight"].shape == (192, 96, 2, 2) \
+        and cx["classifier.2.weight"].shape == (1000, 768) and "features.0.1.bias" in cx and "classifier.0.weight" in cx
     sq = models.create_model("squeezenet1_1").state_dict()
     assert sq["features.3.squeeze.weight"].shape == (16, 64, 1, 1) and sq["classifier.1.weight"].shape == (1000, 512, 1, 1)
     al = models.create_model("alexnet").state_dict()

@@ -357,6 +357,38 @@ def test_smooth_activations_se_gate_and_stochastic_depth(dtype):
     assert F.stochastic_depth(x, 0.25, False) is x
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,C", [((3, 5, 7), 96), ((2, 3, 3), 40), ((1, 2, 2), 8), ((2, 4, 4), 768), ((5,), 1536),
+                                    ((3, 2, 1), 1024), ((4099,), 192)])
+def test_layer_norm_and_gelu(dtype, rows, C):
+    """Row-wise LayerNorm (4 ... 64 lanes per row, up to 4 chunks per lane, ragged last wave) and exact GELU."""
+    if dtype == torch.float32 and C > 1024:
+        pytest.skip("fp32 rows are limited to 256 16-byte chunks")
+    torch.manual_seed(31)
+    x0 = (torch.randn(*rows, C, device=DEV) * 2 + 0.5).to(dtype)
+    w0, b0 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    g0 = torch.randn(*rows, C, device=DEV).to(dtype)
+    x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    y = F.layer_norm(x, w, b, 1e-6)
+    y.backward(g0)
+    xr, wr, br = x0.float().clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = TF.layer_norm(xr, (C,), wr, br, 1e-6)
+    yr.backward(g0.float())
+    _close(y, yr, dtype)
+    _close(x.grad, xr.grad, dtype)
+    nrows = x0.numel() // C
+    _close(w.grad, wr.grad, dtype, scale=max(1.0, nrows ** 0.5 / 8))
+    _close(b.grad, br.grad, dtype, scale=max(1.0, nrows ** 0.5 / 8))
+    x = x0.clone().requires_grad_(True)
+    y = F.activation(x, "gelu")
+    y.backward(g0)
+    xr = x0.float().clone().requires_grad_(True)
+    yr = TF.gelu(xr)
+    yr.backward(g0.float())
+    _close(y, yr, dtype)
+    _close(x.grad, xr.grad, dtype)
+
+
 @pytest.mark.parametrize("lp", [None, torch.bfloat16])
 def test_fused_sgd_matches_torch(lp):
     from distributed_pytorch_amd.optim import FusedSGD

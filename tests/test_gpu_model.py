@@ -26,7 +26,7 @@ def _run(model, x, t):
                                            ("googlenet", 96, 3e-3), ("regnet_x_400mf", 96, 4e-3),
                                            ("regnet_y_400mf", 96, 4e-3), ("mobilenet_v3_small", 96, 4e-3),
                                            ("mobilenet_v3_large", 64, 4e-3), ("efficientnet_b0", 64, 4e-3),
-                                           ("efficientnet_v2_s", 64, 4e-3), ("inception_v3", 171, 6e-3)])
+                                           ("efficientnet_v2_s", 64, 4e-3), ("inception_v3", 171, 6e-3), ("convnext_tiny", 64, 4e-3)])
 def test_fp32_model_matches_cpu_reference(arch, size, tol):
     from distributed_pytorch_amd import amp, models
 
@@ -36,6 +36,9 @@ def test_fp32_model_matches_cpu_reference(arch, size, tol):
     for m in cpu.modules():                      # no dropout / stochastic-depth noise in the comparison
         if m.__class__.__name__ in ("Dropout", "StochasticDepth"):
             m.p = 0.0
+    for n, p in cpu.named_parameters():          # ConvNeXt's 1e-6 layer scale would hide the residual branches
+        if n.endswith("layer_scale"):
+            p.data.fill_(0.5)
     gpu = copy.deepcopy(cpu).cuda()
     x = torch.randn(4, 3, size, size)
     t = torch.randint(0, 1000, (4,))
