@@ -437,6 +437,55 @@ __global__ __launch_bounds__(256) void avgpool_win_bwd_kernel(const T* __restric
   }
 }
 
+// Global average pool (output 1x1: classifier heads, every squeeze-excitation block).  The adaptive kernel above gives
+// one lane a whole H*W column -- 12,544 serial loads at 112x112.  Here a workgroup owns sample n and CL channel chunks;
+// its 256 / CL pixel rows stride over H*W and meet in LDS in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int chunks,
+                                                             int CL) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float red[256][VEC + 1];
+  const int cl = threadIdx.x % CL, pr = threadIdx.x / CL, PR = 256 / CL;
+  const int ch = blockIdx.x * CL + cl;
+  const long n = blockIdx.y;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (ch < chunks) {
+    const T* base = x + (n * HW * (long)chunks + ch) * VEC;
+    int p = pr;
+    for (; p + 3 * PR < HW; p += 4 * PR) {           // four loads in flight per lane
+      Vec16<T> v0, v1, v2, v3;
+      v0.load(base + (long)p * chunks * VEC);
+      v1.load(base + (long)(p + PR) * chunks * VEC);
+      v2.load(base + (long)(p + 2 * PR) * chunks * VEC);
+      v3.load(base + (long)(p + 3 * PR) * chunks * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += (v0.get(j) + v1.get(j)) + (v2.get(j) + v3.get(j));
+    }
+    for (; p < HW; p += PR) {
+      Vec16<T> v;
+      v.load(base + (long)p * chunks * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += v.get(j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  if (pr == 0 && ch < chunks) {
+    const float inv = 1.f / (float)HW;
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = 0.f;
+      for (int r = 0; r < PR; ++r) t += red[r * CL + cl][j];
+      o.set(j, t * inv);
+    }
+    o.store(y + (n * (long)chunks + ch) * VEC);
+  }
+}
+
 inline int grid_for(long n) {
   long b = (n + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -568,6 +617,15 @@ void avgpool_fwd_launch(const void* x, void* y, int NB, int IH, int IW, int C, i
   PoolGeom g{NB, IH, IW, C, OH, OW, 0, 0, 0, 0, 0, 0};
   const long total = (long)NB * OH * OW * (C / (dtype == kF32 ? 4 : 8));
   if (total <= 0) return;
+  if (OH == 1 && OW == 1 && IH * IW >= 16 && NB <= 65535) {
+    const int chunks = C / (dtype == kF32 ? 4 : 8);
+    int CL = 1;
+    while (CL < chunks && CL < 16) CL <<= 1;
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(global_avgpool_kernel<T>, dim3(ceil_div(chunks, CL), NB), dim3(256), 0, s,
+                                                 (const T*)x, (T*)y, IH * IW, chunks, CL));
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s,
                                                (const T*)x, (T*)y, g, total));
   DPA_CHECK_HIP(hipGetLastError());

@@ -200,10 +200,11 @@ def test_max_pool(dtype, k, s, p, H):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("H,o", [(7, 1), (13, 6), (10, 7)])
+@pytest.mark.parametrize("H,o", [(7, 1), (13, 6), (10, 7), (29, 1), (56, 1), (3, 1)])
 def test_avg_pool(dtype, H, o):
     torch.manual_seed(5)
-    x = torch.randn(3, H, H, 64, device=DEV).to(dtype).requires_grad_(True)
+    # 1x1 outputs of extent >= 4 take the parallel global-average kernel (squeeze-excitation at 56x56 ...)
+    x = torch.randn(3, H, H, {29: 40, 56: 8, 3: 136}.get(H, 64), device=DEV).to(dtype).requires_grad_(True)
     y = F.adaptive_avg_pool2d(x, o)
     gy = torch.randn_like(y.float()).to(dtype)
     y.backward(gy)
