@@ -263,6 +263,19 @@ PYBIND11_MODULE(_C, m) {
   m.def("relu_bwd", [](uintptr_t y, uintptr_t dy, uintptr_t dx, long n, int dtype, uintptr_t s) {
     relu_bwd_launch(ptr<const void>(y), ptr<const void>(dy), ptr<void>(dx), n, dtype, st(s));
   });
+  m.def("dw_conv_rows", &dw_conv_rows);
+  m.def("dw_wgrad_rows", &dw_wgrad_rows);
+  m.def("dw_conv", [](uintptr_t in, uintptr_t w, int w_dtype, uintptr_t bias, uintptr_t out, uintptr_t stats, int backward,
+                      int NB, int IH, int IW, int C, int OH, int OW, int KH, int KW, int sh, int sw, int ph, int pw,
+                      int relu, int dtype, uintptr_t s) {
+    dw_conv_launch(ptr<const void>(in), ptr<const void>(w), w_dtype, ptr<const float>(bias), ptr<void>(out),
+                   ptr<float>(stats), backward, NB, IH, IW, C, OH, OW, KH, KW, sh, sw, ph, pw, relu, dtype, st(s));
+  });
+  m.def("dw_wgrad", [](uintptr_t dy, uintptr_t x, uintptr_t partial, int NB, int IH, int IW, int C, int OH, int OW, int KH,
+                       int KW, int sh, int sw, int ph, int pw, int dtype, uintptr_t s) {
+    dw_wgrad_launch(ptr<const void>(dy), ptr<const void>(x), ptr<float>(partial), NB, IH, IW, C, OH, OW, KH, KW, sh, sw,
+                    ph, pw, dtype, st(s));
+  });
   m.def("ln_partial_rows", &ln_partial_rows);
   m.def("ln_fwd", [](uintptr_t x, uintptr_t w, uintptr_t b, uintptr_t y, uintptr_t mean, uintptr_t rstd, long rows, int C,
                      float eps, int dtype, uintptr_t s) {

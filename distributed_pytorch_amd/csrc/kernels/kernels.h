@@ -176,6 +176,14 @@ void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad
 void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
 void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
+// direct depthwise convolution (groups == channels); w = the parameter's memory [C][KH][KW] (fp32 or compute dtype)
+int dw_conv_rows(long npix, int C, int dtype);
+void dw_conv_launch(const void* in, const void* w, int w_dtype, const float* bias, void* out, float* stats, int backward,
+                    int NB, int IH, int IW, int C, int OH, int OW, int KH, int KW, int sh, int sw, int ph, int pw, int relu,
+                    int dtype, hipStream_t s);
+int dw_wgrad_rows(long npix, int C, int KH, int dtype);
+void dw_wgrad_launch(const void* dy, const void* x, float* partial, int NB, int IH, int IW, int C, int OH, int OW, int KH,
+                     int KW, int sh, int sw, int ph, int pw, int dtype, hipStream_t s);
 // LayerNorm over the last axis of [rows][C]; backward folds dgamma / dbeta from ln_partial_rows() partial rows
 int ln_partial_rows(long rows, int C, int dtype);
 void ln_fwd_launch(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, long rows, int C,

@@ -697,8 +697,99 @@ class _GroupConvFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+_DW_DIRECT = os.environ.get("DPA_DW_DIRECT", "1") == "1"
+
+
+def _dw_filter(weight):
+    """The depthwise filter as the kernels read it: memory [C][KH][KW] (fp32 master or compute dtype)."""
+    K, _, R, S = weight.shape
+    w = weight.detach()
+    if w.stride(0) != R * S or w.stride(2) != S or w.stride(3) != 1:
+        w = w.reshape(K, R * S).contiguous()
+    return w
+
+
+class _DepthwiseConvFn(torch.autograd.Function):
+    """groups == channels: direct bandwidth kernels (``csrc/kernels/depthwise.hip``) instead of block-diagonal MFMA
+    tiles.  The filter is read from the parameter itself; the weight gradient is folded from one partial row per
+    workgroup straight into the parameter's gradient sink."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad):
+        x = x if x.is_contiguous() else x.contiguous()
+        NB, IH, IW, Cx = x.shape
+        K, _, R, S = weight.shape
+        sh, sw = stride
+        ph, pw = padding
+        OH, OW = _conv_out(IH, R, sh, ph), _conv_out(IW, S, sw, pw)
+        if OH <= 0 or OW <= 0:
+            raise ValueError("conv2d: input %s too small for kernel %s" % (tuple(x.shape), (R, S)))
+        w = _dw_filter(weight)
+        y = torch.empty((NB, OH, OW, K), dtype=x.dtype, device=x.device)
+        stats = None
+        if want_stats:
+            stats = torch.empty((C().dw_conv_rows(NB * OH * OW, K, _dt(x)), 2, K), dtype=torch.float32, device=x.device)
+        bias_f = None if bias is None else _f32(bias.detach()).contiguous()
+        C().dw_conv(x.data_ptr(), w.data_ptr(), _dt(w), _p(bias_f), y.data_ptr(), _p(stats), 0, NB, IH, IW, K, OH, OW,
+                    R, S, sh, sw, ph, pw, 1 if relu else 0, _dt(x), _stream())
+        ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
+        ctx.bias_ref = bias
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, dstats=None):
+        if dy is None:
+            return (None,) * 8
+        x, weight, y = ctx.saved_tensors
+        (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
+        NB, IH, IW, Cx = x.shape
+        K, _, R, S = weight.shape
+        OH, OW = dy.shape[1], dy.shape[2]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        st = _stream()
+        if relu:
+            dym = torch.empty_like(dy)
+            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
+            dy = dym
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and needs_input_grad:
+            w = _dw_filter(weight)
+            dx = torch.empty((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
+            C().dw_conv(dy.data_ptr(), w.data_ptr(), _dt(w), 0, dx.data_ptr(), 0, 1, NB, IH, IW, K, OH, OW, R, S, sh, sw,
+                        ph, pw, 0, _dt(dy), st)
+        if ctx.needs_input_grad[1]:
+            rows = C().dw_wgrad_rows(NB * OH * OW, K, R, _dt(dy))
+            partial = torch.empty((rows, K, R * S), dtype=torch.float32, device=dy.device)
+            C().dw_wgrad(dy.data_ptr(), x.data_ptr(), partial.data_ptr(), NB, IH, IW, K, OH, OW, R, S, sh, sw, ph, pw,
+                         _dt(dy), st)
+            sink = grad_sink.sink_of(weight)
+            if sink is not None and _flat_same_layout(sink.view, weight) and weight.stride(0) == R * S \
+                    and weight.stride(2) == S and weight.stride(3) == 1:
+                C().slab_reduce(partial.data_ptr(), rows, K * R * S, sink.view.data_ptr(), _dt(weight.dtype),
+                                sink.beta(), st)
+                sink.delivered()
+            else:
+                full = torch.empty((K, 1, R, S), dtype=torch.float32, device=dy.device)
+                C().slab_reduce(partial.data_ptr(), rows, K * R * S, full.data_ptr(), 0, 0.0, st)
+                dw = _deliver(weight, full.to(weight.dtype))
+        if has_bias and ctx.needs_input_grad[2]:
+            bias_p = ctx.bias_ref
+            db = _deliver(bias_p, _colsum(dy.view(NB * OH * OW, K)).to(bias_p.dtype))
+        return dx, dw, db, None, None, None, None, None
+
+
 def group_conv2d(x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad=True):
     grad_sink.note_use(weight, bias)
+    K, Cg, R, S = weight.shape
+    if _DW_DIRECT and groups == K and Cg == 1 and x.shape[-1] == K and R <= 7 and S <= 7 \
+            and weight.dtype in (torch.float32, x.dtype):
+        y, stats = _DepthwiseConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
+                                          bool(needs_input_grad))
+        return (y, stats) if want_stats else y
     y, stats = _GroupConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), int(groups), bool(relu),
                                   bool(want_stats), bool(needs_input_grad))
     return (y, stats) if want_stats else y

@@ -523,6 +523,11 @@ GROUP_CASES = [
     (2, 8, 8, 64, 128, 4, 1, 1, 0),         # grouped 1x1 (wgrad linear fast path)
     (2, 14, 14, 72, 72, 3, 3, 1, 1),        # RegNetX-1.6GF: 24 channels per group, K tiles straddle taps
     (2, 14, 14, 400, 400, 25, 3, 2, 1),     # RegNetX-400MF last stage: 25 groups of 16, unmerged
+    (2, 14, 14, 40, 40, 40, 5, 2, 2),       # direct depthwise kernels: 5x5 stride 2 (MNASNet / EfficientNet)
+    (2, 12, 12, 96, 96, 96, 7, 1, 3),       # ConvNeXt 7x7
+    (3, 9, 9, 8, 8, 8, 3, 1, 1),            # a single 16-byte chunk
+    (2, 28, 28, 144, 144, 144, 3, 2, 1),    # two channel slabs, ragged second one
+    (130, 5, 5, 24, 24, 24, 3, 1, 1),       # many images, tiny extent
 ]
 
 
@@ -558,6 +563,28 @@ def test_group_conv_fwd_bwd(case, dtype, bias_relu):
     _close(w.grad, wr.grad, dtype, what="wgrad")
     if b is not None:
         _close(b.grad, br.grad, dtype, what="bias grad")
+
+
+def test_depthwise_direct_equals_block_diagonal_path():
+    """DPA_DW_DIRECT=0 keeps depthwise convolutions on the grouped implicit-GEMM kernels; both paths agree."""
+    from distributed_pytorch_amd.ops import hip_ops
+
+    torch.manual_seed(6)
+    x0 = torch.randn(2, 14, 14, 96, device=DEV).to(torch.bfloat16)
+    w0 = (torch.randn(96, 1, 3, 3, device=DEV) / 3).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 7, 7, 96, device=DEV).to(torch.bfloat16)
+    res = []
+    try:
+        for direct in (True, False):
+            hip_ops._DW_DIRECT = direct
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y, stats = F.conv2d(x, w, None, 2, 1, groups=96, want_stats=True)
+            y.backward(gy)
+            res.append((y.detach(), stats.sum(0), x.grad, w.grad))
+    finally:
+        hip_ops._DW_DIRECT = True
+    for a, b in zip(*res):
+        _close(a, b, torch.bfloat16)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
