@@ -26,10 +26,27 @@ struct DwGeom {
 constexpr int kDwMaxTaps = 49;
 constexpr int kDwSlab = 8;          // channel chunks per workgroup
 
-template <typename T, typename TW, bool BWD, int KWT>
+// source coordinate of tap `t` for written coordinate `p`: fprop p*st - pad + t; backward-data (p + pad - t) / st when
+// that lands on the stride lattice
+template <bool BWD>
+__device__ __forceinline__ bool dw_src(int p, int t, int st, int pad, int extent, int& src) {
+  if (BWD) {
+    const int u = p + pad - t;
+    if (st == 1) src = u;
+    else if (st == 2) src = u >> 1;
+    else src = u / st;
+    return u >= 0 && src * st == u && src < extent;
+  }
+  src = p * st - pad + t;
+  return src >= 0 && src < extent;
+}
+
+// KHT > 0: the whole KHT x KWT window is loaded up front (3x3, 5x5); KHT == 0: one filter row at a time (7x7, odd shapes)
+template <typename T, typename TW, bool BWD, int KWT, int KHT>
 __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, const TW* __restrict__ w,
                                                       const float* __restrict__ bias, T* __restrict__ out,
-                                                      float* __restrict__ stats, DwGeom g, int CSL, int relu) {
+                                                      float* __restrict__ stats, DwGeom g, int CSL, int relu,
+                                                      FastDiv div_w, FastDiv div_h) {
   constexpr int VEC = 16 / (int)sizeof(T);
   __shared__ float wl[kDwMaxTaps][kDwSlab * VEC];
   __shared__ float red[2][256][VEC + 1];
@@ -47,58 +64,73 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
   // out pixels: fprop -> (n, oy, ox) over OH x OW; backward-data -> (n, iy, ix) over IH x IW
   const int PH = BWD ? g.IH : g.OH, PW = BWD ? g.IW : g.OW;     // extents of the tensor being written
   const int SH = BWD ? g.OH : g.IH, SW = BWD ? g.OW : g.IW;     // extents of the tensor being read
-  const long npix = (long)g.NB * PH * PW;
+  const uint32_t npix = (uint32_t)g.NB * PH * PW;              // < 2^31, checked by the launcher
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
   const bool active = ch < chunks;
-  for (long pix = (long)blockIdx.x * PXL + pl; pix < npix; pix += (long)gridDim.x * PXL) {
+  const int st_y = g.sh, st_x = g.sw;
+  for (uint32_t pix = blockIdx.x * PXL + pl; pix < npix; pix += gridDim.x * PXL) {
     if (!active) continue;
-    const int px = (int)(pix % PW);
-    const long q = pix / PW;
-    const int py = (int)(q % PH);
-    const long n = q / PH;
+    const uint32_t q = fdiv(pix, div_w);
+    const int px = (int)(pix - q * PW);
+    const uint32_t n = fdiv(q, div_h);
+    const int py = (int)(q - n * PH);
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = (!BWD && bias != nullptr) ? bias[ch * VEC + j] : 0.f;
-    const T* base = in + n * SH * SW * (long)g.C + ch * VEC;
-    for (int r = 0; r < g.KH; ++r) {
-      int sy;
-      bool oky;
-      if (BWD) {
-        const int ty = py + g.ph - r;
-        sy = ty / g.sh;
-        oky = ty >= 0 && sy * g.sh == ty && sy < SH;
-      } else {
-        sy = py * g.sh - g.ph + r;
-        oky = sy >= 0 && sy < SH;
-      }
-      if (!oky) continue;
-      const T* row = base + (long)sy * SW * g.C;
-      const float* wr = &wl[r * g.KW][cl * VEC];
-      // the whole filter row in flight at once: loads from clamped addresses, masks applied at the multiply
-      // (a tap loop with data-dependent skips would serialise one memory latency per tap)
-      Vec16<T> v[KWT];
+    const T* base = in + (long)n * SH * SW * g.C + ch * VEC;
+    if constexpr (KHT > 0) {
+      // every tap of the window in flight at once: loads from clamped addresses, masks applied at the multiply
+      Vec16<T> v[KHT][KWT];
+      bool ok[KHT][KWT];
+      int sx[KWT];
       bool okx[KWT];
 #pragma unroll
-      for (int s = 0; s < KWT; ++s) {
-        int sx;
-        if (BWD) {
-          const int tx = px + g.pw - s;
-          sx = tx / g.sw;
-          okx[s] = s < g.KW && tx >= 0 && sx * g.sw == tx && sx < SW;
-        } else {
-          sx = px * g.sw - g.pw + s;
-          okx[s] = s < g.KW && sx >= 0 && sx < SW;
+      for (int s = 0; s < KWT; ++s) okx[s] = dw_src<BWD>(px, s, st_x, g.pw, SW, sx[s]);
+#pragma unroll
+      for (int r = 0; r < KHT; ++r) {
+        int sy;
+        const bool oky = dw_src<BWD>(py, r, st_y, g.ph, SH, sy);
+        const T* row = base + (long)(oky ? sy : 0) * SW * g.C;
+#pragma unroll
+        for (int s = 0; s < KWT; ++s) {
+          ok[r][s] = oky && okx[s];
+          v[r][s].load(row + (long)(okx[s] ? sx[s] : 0) * g.C);
         }
-        v[s].load(row + (long)(okx[s] ? sx : 0) * g.C);
       }
 #pragma unroll
-      for (int s = 0; s < KWT; ++s) {
-        if (okx[s]) {
-          const float* wt = wr + s * (kDwSlab * VEC);
+      for (int r = 0; r < KHT; ++r)
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) acc[j] += v[s].get(j) * wt[j];
+        for (int s = 0; s < KWT; ++s) {
+          if (ok[r][s]) {
+            const float* wt = &wl[r * KWT + s][cl * VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += v[r][s].get(j) * wt[j];
+          }
+        }
+    } else {
+      for (int r = 0; r < g.KH; ++r) {
+        int sy;
+        if (!dw_src<BWD>(py, r, st_y, g.ph, SH, sy)) continue;
+        const T* row = base + (long)sy * SW * g.C;
+        // the whole filter row in flight at once (a tap loop with data-dependent skips would serialise one
+        // memory latency per tap)
+        Vec16<T> v[KWT];
+        bool okx[KWT];
+#pragma unroll
+        for (int s = 0; s < KWT; ++s) {
+          int sx;
+          okx[s] = s < g.KW && dw_src<BWD>(px, s, st_x, g.pw, SW, sx);
+          v[s].load(row + (long)(okx[s] ? sx : 0) * g.C);
+        }
+#pragma unroll
+        for (int s = 0; s < KWT; ++s) {
+          if (okx[s]) {
+            const float* wt = &wl[r * g.KW + s][cl * VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += v[s].get(j) * wt[j];
+          }
         }
       }
     }
@@ -114,7 +146,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
         s2[j] += rv * rv;
       }
     }
-    o.store(out + pix * g.C + ch * VEC);
+    o.store(out + (long)pix * g.C + ch * VEC);
   }
   if (!BWD && stats != nullptr) {
 #pragma unroll
@@ -141,7 +173,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
 // lanes: cl (channel chunk of the slab) fastest, then filter row r, then pixel lane pl
 template <typename T, int KW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                       float* __restrict__ partial, DwGeom g, int CSL, int PL) {
+                                                       float* __restrict__ partial, DwGeom g, int CSL, int PL,
+                                                       FastDiv div_w, FastDiv div_h) {
   constexpr int VEC = 16 / (int)sizeof(T);
   __shared__ float red[256][VEC + 1];
   const int chunks = g.C / VEC;
@@ -150,39 +183,48 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy,
   const int cl = threadIdx.x % CSL, r = (threadIdx.x / CSL) % g.KH, pl = threadIdx.x / lanes;
   const int ch = blockIdx.y * CSL + cl;
   const bool active = pl < PL && ch < chunks;
-  const long npix = (long)g.NB * g.OH * g.OW;
+  const uint32_t npix = (uint32_t)g.NB * g.OH * g.OW;          // < 2^31, checked by the launcher
   float acc[KW][VEC];
 #pragma unroll
   for (int s = 0; s < KW; ++s)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[s][j] = 0.f;
   if (active) {
-    for (long pix = (long)blockIdx.x * PL + pl; pix < npix; pix += (long)gridDim.x * PL) {
-      const int ox = (int)(pix % g.OW);
-      const long q = pix / g.OW;
-      const int oy = (int)(q % g.OH);
-      const long n = q / g.OH;
-      const int iy = oy * g.sh - g.ph + r;
-      if (iy < 0 || iy >= g.IH) continue;
-      Vec16<T> gv;
-      gv.load(dy + pix * g.C + ch * VEC);
-      const T* row = x + ((n * g.IH + iy) * (long)g.IW) * g.C + ch * VEC;
-      const int ix0 = ox * g.sw - g.pw;
-      Vec16<T> xv[KW];
-      bool ok[KW];
+    // two pixels per iteration: 2 * (1 + KW) independent 16-byte loads in flight per lane
+    const uint32_t step = gridDim.x * PL;
+    for (uint32_t pix0 = blockIdx.x * PL + pl; pix0 < npix; pix0 += 2 * step) {
+      Vec16<T> gv[2], xv[2][KW];
+      bool ok[2][KW];
 #pragma unroll
-      for (int s = 0; s < KW; ++s) {           // all loads of the filter row in flight, clamped addresses
-        const int ix = ix0 + s;
-        ok[s] = s < g.KW && ix >= 0 && ix < g.IW;
-        xv[s].load(row + (long)(ok[s] ? ix : 0) * g.C);
-      }
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t pix = pix0 + u * step;
+        const bool live = pix < npix;
+        const uint32_t pc = live ? pix : pix0;
+        const uint32_t q = fdiv(pc, div_w);
+        const int ox = (int)(pc - q * g.OW);
+        const uint32_t n = fdiv(q, div_h);
+        const int oy = (int)(q - n * g.OH);
+        const int iy = oy * g.sh - g.ph + r;
+        const bool oky = live && iy >= 0 && iy < g.IH;
+        gv[u].load(dy + (long)pc * g.C + ch * VEC);
+        const T* row = x + (((long)n * g.IH + (oky ? iy : 0)) * g.IW) * g.C + ch * VEC;
+        const int ix0 = ox * g.sw - g.pw;
 #pragma unroll
-      for (int s = 0; s < KW; ++s) {
-        if (ok[s]) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) acc[s][j] += gv.get(j) * xv[s].get(j);
+        for (int s = 0; s < KW; ++s) {           // clamped addresses, masks at the multiply
+          const int ix = ix0 + s;
+          ok[u][s] = oky && s < g.KW && ix >= 0 && ix < g.IW;
+          xv[u][s].load(row + (long)(ok[u][s] ? ix : 0) * g.C);
         }
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+          if (ok[u][s]) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[s][j] += gv[u].get(j) * xv[u][s].get(j);
+          }
+        }
     }
   }
   // pixel lanes meet in LDS, one tap column at a time (fixed order)
@@ -244,20 +286,24 @@ void dw_conv_launch(const void* in, const void* w, int w_dtype, const float* bia
   const long npix = (long)NB * (backward ? IH * IW : OH * OW);
   if (npix <= 0) return;
   dim3 grid(dw_conv_rows(npix, C, dtype), ceil_div(chunks, CSL));
-#define DPA_DW(BW, KWT)                                                                                               \
+  if (npix >= (1L << 31)) throw std::invalid_argument("depthwise: more than 2^31 pixels");
+  const FastDiv div_w = make_fastdiv((uint32_t)(backward ? IW : OW)), div_h = make_fastdiv((uint32_t)(backward ? IH : OH));
+#define DPA_DW(BW, KWT, KHT)                                                                                          \
   DPA_DISPATCH_DTYPE(dtype, {                                                                                         \
     if (w_dtype == kF32)                                                                                              \
-      hipLaunchKernelGGL((dw_conv_kernel<T, float, BW, KWT>), grid, dim3(256), 0, s, (const T*)in, (const float*)w, bias,   \
-                         (T*)out, stats, g, CSL, relu);                                                               \
+      hipLaunchKernelGGL((dw_conv_kernel<T, float, BW, KWT, KHT>), grid, dim3(256), 0, s, (const T*)in, (const float*)w,    \
+                         bias, (T*)out, stats, g, CSL, relu, div_w, div_h);                                           \
     else                                                                                                              \
-      hipLaunchKernelGGL((dw_conv_kernel<T, T, BW, KWT>), grid, dim3(256), 0, s, (const T*)in, (const T*)w, bias, (T*)out,  \
-                         stats, g, CSL, relu);                                                                        \
+      hipLaunchKernelGGL((dw_conv_kernel<T, T, BW, KWT, KHT>), grid, dim3(256), 0, s, (const T*)in, (const T*)w, bias,      \
+                         (T*)out, stats, g, CSL, relu, div_w, div_h);                                                 \
   })
-#define DPA_DW_KW(BW)                       \
-  if (KW <= 1) { DPA_DW(BW, 1); }           \
-  else if (KW <= 3) { DPA_DW(BW, 3); }      \
-  else if (KW <= 5) { DPA_DW(BW, 5); }      \
-  else { DPA_DW(BW, 7); }
+#define DPA_DW_KW(BW)                                     \
+  if (KH == 3 && KW == 3) { DPA_DW(BW, 3, 3); }           \
+  else if (KH == 5 && KW == 5) { DPA_DW(BW, 5, 5); }      \
+  else if (KW <= 1) { DPA_DW(BW, 1, 0); }                 \
+  else if (KW <= 3) { DPA_DW(BW, 3, 0); }                 \
+  else if (KW <= 5) { DPA_DW(BW, 5, 0); }                 \
+  else { DPA_DW(BW, 7, 0); }
   if (backward) { DPA_DW_KW(true) } else { DPA_DW_KW(false) }
 #undef DPA_DW_KW
 #undef DPA_DW
@@ -284,10 +330,12 @@ void dw_wgrad_launch(const void* dy, const void* x, float* partial, int NB, int 
   const int PL = 256 / (CSL * KH);
   const long npix = (long)NB * OH * OW;
   if (npix <= 0 || PL < 1) throw std::invalid_argument("depthwise wgrad: empty problem");
+  if (npix >= (1L << 31)) throw std::invalid_argument("depthwise: more than 2^31 pixels");
+  const FastDiv div_w = make_fastdiv((uint32_t)OW), div_h = make_fastdiv((uint32_t)OH);
   dim3 grid(dw_wgrad_rows(npix, C, KH, dtype), ceil_div(chunks, CSL));
 #define DPA_DWW(KWT)                                                                                              \
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dw_wgrad_kernel<T, KWT>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, \
-                                               partial, g, CSL, PL))
+                                               partial, g, CSL, PL, div_w, div_h))
   if (KW <= 1) { DPA_DWW(1); }
   else if (KW <= 3) { DPA_DWW(3); }
   else if (KW <= 5) { DPA_DWW(5); }
