@@ -1,0 +1,62 @@
+"""CPU reference backend: one tiny training step of every zoo family (forward, loss, backward) -- every parameter gets
+a finite gradient, eval mode returns logits, and the functional ops added for the newer families agree with torch."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from distributed_pytorch_amd import models
+from distributed_pytorch_amd.ops import functional as F
+
+FAMILIES = [("resnet18", 64), ("resnext50_32x4d", 64), ("alexnet", 96), ("vgg11_bn", 32), ("squeezenet1_1", 64),
+            ("densenet121", 64), ("mobilenet_v2", 64), ("mobilenet_v3_small", 64), ("mnasnet0_5", 64), ("googlenet", 64),
+            ("inception_v3", 107), ("regnet_x_400mf", 64), ("regnet_y_400mf", 64), ("efficientnet_b0", 64),
+            ("efficientnet_v2_s", 64), ("convnext_tiny", 64)]
+
+
+@pytest.mark.parametrize("arch,size", FAMILIES)
+def test_family_trains_one_step_on_cpu(arch, size):
+    torch.manual_seed(0)
+    m = models.create_model(arch, num_classes=7).train()
+    x = torch.randn(2, 3, size, size)
+    t = torch.randint(0, 7, (2,))
+    loss, rec = F.loss_and_metrics(m(x), t)
+    loss.backward()
+    assert torch.isfinite(loss) and rec.shape == (4,)
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    m.eval()
+    with torch.no_grad():
+        assert m(x).shape == (2, 7)
+
+
+def test_registry_is_the_arch_choice_list():
+    names = models.list_models()
+    assert len(names) == 64 and names == sorted(names)
+    for fam in ("resnet50", "vgg16_bn", "densenet201", "mobilenet_v3_large", "efficientnet_b7", "efficientnet_v2_l",
+                "regnet_y_128gf", "convnext_large", "inception_v3", "googlenet", "mnasnet1_3", "squeezenet1_0",
+                "wide_resnet101_2", "resnext101_64x4d"):
+        assert fam in names, fam
+    with pytest.raises(KeyError):
+        models.create_model("not_a_model")
+
+
+def test_new_functional_ops_cpu_reference():
+    torch.manual_seed(1)
+    x = torch.randn(2, 5, 6, 16)
+    for kind, fn in (("sigmoid", torch.sigmoid), ("silu", TF.silu), ("hardsigmoid", TF.hardsigmoid),
+                     ("hardswish", TF.hardswish), ("gelu", TF.gelu)):
+        assert torch.equal(F.activation(x, kind), fn(x))
+    with pytest.raises(ValueError):
+        F.activation(x, "swishish")
+    s = torch.rand(2, 16)
+    assert torch.allclose(F.se_scale(x, s), x * s[:, None, None, :])
+    w, b = torch.rand(16) + 0.5, torch.randn(16)
+    assert torch.allclose(F.layer_norm(x, w, b, 1e-6), TF.layer_norm(x, (16,), w, b, 1e-6), atol=1e-6)
+    assert torch.equal(F.add(x, x), x + x)
+    assert F.stochastic_depth(x, 0.3, False) is x and F.stochastic_depth(x, 0.0, True) is x
+    y = F.stochastic_depth(torch.ones(4000, 1, 1, 8), 0.3, True)
+    kept = (y[:, 0, 0, 0] != 0).float().mean().item()
+    assert 0.65 < kept < 0.75 and torch.allclose(y[y != 0], torch.tensor(1 / 0.7))
+    ref = TF.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1)
+    assert torch.allclose(F.avg_pool2d(x, 3, 1, 1), ref)
+    assert F.avg_pool2d(x[:, :4], 2, 2).shape == (2, 2, 3, 16)
