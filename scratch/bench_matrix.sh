@@ -19,4 +19,16 @@ run --arch mobilenet_v2 --batch-size 256
 run --arch mnasnet1_0 --batch-size 256
 run --arch regnet_x_1_6gf --batch-size 256
 run --arch regnet_x_8gf --batch-size 256
+run --arch regnet_y_400mf --batch-size 256
+run --arch regnet_y_1_6gf --batch-size 256
+run --arch regnet_y_8gf --batch-size 128
+run --arch mobilenet_v3_large --batch-size 256
+run --arch mobilenet_v3_small --batch-size 256
+run --arch efficientnet_b0 --batch-size 256
+run --arch efficientnet_b3 --batch-size 128
+run --arch efficientnet_v2_s --batch-size 128
+run --arch inception_v3 --batch-size 128 --image-size 299
+run --arch convnext_tiny --batch-size 128
+run --arch convnext_base --batch-size 64
+run --force-ddp
 DPA_TORCH_BASELINE=1 run --batch-size 256
