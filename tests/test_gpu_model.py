@@ -56,6 +56,33 @@ def test_fp32_model_matches_cpu_reference(arch, size, tol):
         assert rel < 10 * tol, (n, rel)
 
 
+@pytest.mark.parametrize("arch,size", [("resnet50", 96), ("densenet121", 64), ("googlenet", 96), ("mobilenet_v3_small", 96),
+                                       ("efficientnet_b0", 64), ("regnet_y_400mf", 96), ("inception_v3", 171),
+                                       ("convnext_tiny", 64), ("vgg11", 64)])
+def test_eval_mode_matches_cpu_reference(arch, size):
+    """model.eval() (validate(): BN from running statistics, no dropout / stochastic depth) after one training step
+    that moved the running statistics: same logits on the CPU reference backend and on the HIP backend."""
+    from distributed_pytorch_amd import amp, models
+
+    amp.state().reset()
+    torch.manual_seed(0)
+    cpu = models.create_model(arch, num_classes=100)
+    for m in cpu.modules():
+        if m.__class__.__name__ in ("Dropout", "StochasticDepth"):
+            m.p = 0.0
+    gpu = copy.deepcopy(cpu).cuda()
+    x = torch.randn(4, 3, size, size)
+    with torch.no_grad():
+        cpu.train()(x)
+        gpu.train()(x.cuda())                    # running_mean / running_var / num_batches_tracked now differ from init
+        o1 = cpu.eval()(x)
+        o2 = gpu.eval()(x.cuda()).float().cpu()
+    for (n, b1), (_, b2) in zip(cpu.named_buffers(), gpu.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float().cpu(), rtol=2e-3, atol=2e-4), n
+    assert o2.shape == (4, 100) and torch.isfinite(o2).all()
+    assert (o1 - o2).abs().max() < 4e-3 * max(1.0, o1.abs().max())
+
+
 def test_bf16_training_reduces_loss_and_tracks_fp32():
     from distributed_pytorch_amd import amp, models
     from distributed_pytorch_amd.ops import functional as F
