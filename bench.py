@@ -156,7 +156,8 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic uint8 224x224 from pinned host memory, random-init weights",
+            "dtype": args.dtype,
+            "data": "synthetic uint8 %dx%d from pinned host memory, random-init weights" % (args.image_size, args.image_size),
             "final_loss": final_loss,
             "config": {"model": args.arch, "global_batch": args.batch_size * world,
                        "per_gpu_batch": args.batch_size, "seq_len": None, "image_size": args.image_size,
