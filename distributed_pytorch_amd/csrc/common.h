@@ -119,6 +119,26 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
   return base + i;
 }
 
+// ---- smooth activations: 1 sigmoid, 2 SiLU, 3 hard-sigmoid, 4 hard-swish, 5 GELU (erf) -------------------------
+__device__ __forceinline__ float act_value(int act, float x) {
+  switch (act) {
+    case 1: return 1.f / (1.f + __expf(-x));
+    case 2: return x / (1.f + __expf(-x));
+    case 3: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    case 5: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    default: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  }
+}
+__device__ __forceinline__ float act_slope(int act, float x) {
+  switch (act) {
+    case 1: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
+    case 2: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case 3: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
+    case 5: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    default: return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f));   // ATen's convention at +-3
+  }
+}
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dpa

@@ -24,7 +24,10 @@ namespace {
 constexpr int kBnThreads = 256;
 
 // MODE 0: (sum x, sum x^2).  MODE 1: (sum dy_m, sum dy_m * xhat) with dy_m = dy * (y > 0) if relu.
-template <typename T, int MODE>
+// SMOOTH (MODE 1 only): the BN is followed by a smooth activation ((relu >> 4) & 7, see common.h act_slope) fused into
+// the apply pass; dy is multiplied by its slope at z = scale*x + shift, recomputed here.  A separate instantiation, so
+// the ReLU / no-activation kernels of the ResNet hot path are not touched.
+template <typename T, int MODE, bool SMOOTH = false>
 __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ x,
                                                                 const T* __restrict__ y, long M, int C,
                                                                 const float* __restrict__ mean,
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
     for (int j = 0; j < VEC; ++j) {
       mu[j] = mean[c0 + j];
       is[j] = invstd[c0 + j];
-      if (rm == 2) {
+      if (rm == 2 || SMOOTH) {
         sc[j] = scale[c0 + j];
         sh[j] = shift[c0 + j];
       }
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
           const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
           if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
         }
+        if constexpr (SMOOTH) d *= act_slope((relu >> 4) & 7, sc[j] * xv + sh[j]);
         const float xh = (xv - mu[j]) * is[j];
         s1[j] += d;
         s2[j] += d * xh;
@@ -374,7 +378,7 @@ inline bool nt_auto(long bytes, int who) {
 int g_bn_reverse = 0;        // 1: the apply kernels walk their tensors from the END (what the producer wrote last
                              // is still in the Infinity Cache / L2)
 
-template <typename T, int U>
+template <typename T, int U, bool SMOOTH = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        T* __restrict__ y, long nchunks, int cc,
                                                        const float* __restrict__ scale,
@@ -427,8 +431,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         for (int j = 0; j < VEC; ++j) {
           float v = vx[u].get(j) * scv[j] + shv[j];
           if (res != nullptr) v += vr[u].get(j) * rsc[j] + rsh[j];
-          if (relu) v = fmaxf(v, 0.f);
-          if (relu & 4) v = fminf(v, 6.f);
+          if constexpr (SMOOTH) {
+            v = act_value((relu >> 4) & 7, v);
+          } else {
+            if (relu) v = fmaxf(v, 0.f);
+            if (relu & 4) v = fminf(v, 6.f);
+          }
           vo.set(j, v);
         }
         if (nts) vo.store_nt(y + (i + u * stride) * VEC);
@@ -464,8 +472,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     for (int j = 0; j < VEC; ++j) {
       float v = vx.get(j) * scv[j] + shv[j];
       if (res != nullptr) v += vr.get(j) * rsc[j] + rsh[j];
-      if (relu) v = fmaxf(v, 0.f);
-      if (relu & 4) v = fminf(v, 6.f);
+      if constexpr (SMOOTH) {
+        v = act_value((relu >> 4) & 7, v);
+      } else {
+        if (relu) v = fmaxf(v, 0.f);
+        if (relu & 4) v = fminf(v, 6.f);
+      }
       vo.set(j, v);
     }
     if (nts) vo.store_nt(y + q * VEC);
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_fused_kernel(
   }
 }
 
-template <typename T>
+template <typename T, bool SMOOTH = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, T* __restrict__ dx,
                                                            T* __restrict__ dres, long nchunks, int cc, int C,
@@ -584,6 +596,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
         if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
       }
+      if constexpr (SMOOTH) d *= act_slope((relu >> 4) & 7, sc[j] * xv + sh[j]);
       vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
       vr.set(j, d);
     }
@@ -616,6 +629,14 @@ void col_reduce(const void* a, const void* x, const void* y, long M, int C, int 
   const int gy = ceil_div(C / vec, kBnThreads);
   const long rpb = (M + nblk - 1) / nblk;
   dim3 grid(nblk, gy);
+  if (MODE == 1 && ((relu >> 4) & 7) != 0) {
+    if (scale == nullptr || shift == nullptr) throw std::invalid_argument("bn: a fused activation needs scale / shift");
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col_reduce_kernel<T, MODE, MODE == 1>), grid, dim3(kBnThreads), 0, s,
+                                                 (const T*)a, (const T*)x, (const T*)y, M, C, mean, invstd, relu, scale,
+                                                 shift, partial, rpb));
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
   if (dtype == kF32)
     hipLaunchKernelGGL((col_reduce_kernel<float, MODE>), grid, dim3(kBnThreads), 0, s, (const float*)a,
                        (const float*)x, (const float*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
@@ -698,6 +719,14 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   if (nchunks <= 0) return;
   const int grid = grid_for(nchunks);
   const bool nt = nt_auto(nchunks * 16, 1);
+  if (((relu >> 4) & 7) != 0) {        // BN + smooth activation (SiLU, hard-swish, ...) in one pass
+    if (mask != nullptr) throw std::invalid_argument("bn_apply: no bit mask with a smooth activation");
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 1, true>), dim3(grid), dim3(256), 0, s, (const T*)x,
+                                                 (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu,
+                                                 (g_bn_reverse & 1) | (nt ? 6 : 0), mask, res_scale, res_shift));
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
                                                  (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask, res_scale, res_shift));
@@ -735,6 +764,13 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
   const int grid = grid_for(nchunks);
+  if (((relu >> 4) & 7) != 0) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)dy,
+                                                 (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C, coef,
+                                                 relu, ((g_bn_reverse >> 1) & 1) | (nt_auto(nchunks * 16, 2) ? 6 : 0)));
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C,
                                                coef, relu, ((g_bn_reverse >> 1) & 1) | (nt_auto(nchunks * 16, 2) ? 6 : ((g_bn_reverse >> 4) & 3) << 1)));

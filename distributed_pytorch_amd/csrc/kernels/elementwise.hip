@@ -149,25 +149,6 @@ void ew_launch(const void* a, const void* b, void* y, long n, hipStream_t s) {
 // act: 1 sigmoid, 2 SiLU (x * sigmoid(x)), 3 hard-sigmoid (relu6(x + 3) / 6), 4 hard-swish (x * hard-sigmoid(x)),
 // 5 GELU (exact, erf).
 // Backward recomputes the derivative from the saved INPUT, so no activation-sized mask / output is kept.
-__device__ __forceinline__ float act_value(int act, float x) {
-  switch (act) {
-    case 1: return 1.f / (1.f + __expf(-x));
-    case 2: return x / (1.f + __expf(-x));
-    case 3: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
-    case 5: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-    default: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
-  }
-}
-__device__ __forceinline__ float act_slope(int act, float x) {
-  switch (act) {
-    case 1: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
-    case 2: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
-    case 3: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
-    case 5: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-    default: return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f));   // ATen's convention at +-3
-  }
-}
-
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out,
                                                   long nchunks, int act) {

@@ -298,7 +298,7 @@ def conv_bn_relu_maxpool(x, conv: Conv2d, bn: BatchNorm2d, pool: "MaxPool2d"):
 def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False, defer: bool = False,
                 act: Optional[str] = None):
     """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  ``act`` ("silu", "hardswish", ...): a smooth activation
-    instead of ReLU, applied by its own elementwise kernel after the (activation-free) BN pass.  ``defer=True`` (downsample branches, ``relu=False``): the
+    instead of ReLU, fused into the BN pass like ReLU is.  ``defer=True`` (downsample branches, ``relu=False``): the
     result may only be used as the ``residual`` of the block's last ``conv_bn_act`` (see ``F.batch_norm``).  On the GPU the conv epilogue emits the
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
     re-read for statistics.  ``skip=True`` -> ``(out, x_alias)`` (see ``F.conv2d``)."""
@@ -308,12 +308,10 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip
     if skip:
         out, alias = out
     if act is not None:
-        relu = False
+        relu = act               # applied inside the BN pass (``F.batch_norm(relu="silu")``)
     if fuse:
         y, stats = out
         res = bn(y, relu=relu, residual=residual, stats=stats, defer=defer)
     else:
         res = bn(out, relu=relu, residual=residual, defer=defer)
-    if act is not None:
-        res = F.activation(res, act)
     return (res, alias) if skip else res

@@ -108,7 +108,9 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
     """Fused ``BN [+ residual] [+ ReLU]`` over NHWC (N-K4/K5/K7; SyncBN when
     ``group`` is a process group: N-K6).  Statistics are always fp32.
     ``running_var`` receives the unbiased variance, as in torch / cuDNN.
-    ``relu=6`` applies ReLU6 (MobileNet) inside the same pass.
+    ``relu=6`` applies ReLU6 (MobileNet) inside the same pass; ``relu="silu"`` / ``"hardswish"`` / ... a smooth
+    activation (EfficientNet, MobileNetV3): the GPU training path applies it inside the normalise pass and folds its
+    slope into the BN backward kernels, so no separate activation pass runs in either direction.
     ``defer=True`` (activation-free BN of a downsample branch): on the GPU in training mode nothing is written --
     the result aliases ``x`` and MUST only be used as the ``residual`` of another ``batch_norm``, which applies this
     BN's scale / shift on the fly (one activation-sized write and read less).  Ignored elsewhere.
@@ -129,7 +131,9 @@ def batch_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
                           training, momentum, eps).to(x.dtype).permute(0, 2, 3, 1)
     if residual is not None:
         y = y + residual
-    if relu:
+    if isinstance(relu, str):
+        y = _CPU_ACTS[relu](y)
+    elif relu:
         y = TF.relu6(y) if (relu is not True and relu == 6) else TF.relu(y)
     return y.contiguous()
 

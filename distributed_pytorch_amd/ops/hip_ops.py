@@ -856,6 +856,13 @@ class _BNFn(torch.autograd.Function):
         M = x.numel() // Cc
         st = _stream()
         dev = x.device
+        # relu >= 16: a smooth activation (ACT_CODES << 4) applied inside the normalise pass; backward multiplies dy by
+        # its slope at the recomputed pre-activation inside the BN reduce / apply kernels (no activation pass at all)
+        act = relu >> 4
+        if act:
+            relu = 0
+            if residual is not None:
+                raise ValueError("batch_norm: a smooth activation cannot be combined with a residual")
         if stats is None:
             nblk = C().bn_partial_rows(M, Cc)
             stats = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
@@ -885,7 +892,7 @@ class _BNFn(torch.autograd.Function):
                                  g32.data_ptr(), b32.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
                                  _p(nbt), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
                                  coef[3].data_ptr(), st)
-        if defer and not relu and residual is None and world == 1:
+        if defer and not relu and not act and residual is None and world == 1:
             # Deferred: nothing is written.  The result is an alias of the raw input carrying this BN's (scale,
             # shift); the BatchNorm that takes it as `residual` applies them on the fly.  Backward is the normal one.
             ctx.save_for_backward(x, None, weight, coef, count_dev)
@@ -911,7 +918,7 @@ class _BNFn(torch.autograd.Function):
             relu_mode = 3
             mask = torch.empty(x.numel() // _vec(x.dtype), dtype=torch.uint8, device=dev)
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(),
-                     coef[3].data_ptr(), (1 if relu else 0) | clip, st, _p(mask),
+                     coef[3].data_ptr(), (1 if relu else 0) | clip | (act << 4), st, _p(mask),
                      res_coef[2].data_ptr() if res_coef is not None else 0,
                      res_coef[3].data_ptr() if res_coef is not None else 0)
         ctx.res_coef = res_coef                 # keeps the deferred BN's coefficients alive until backward is done
@@ -923,8 +930,8 @@ class _BNFn(torch.autograd.Function):
         # mask as its own "ReLU" mask
         ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and residual.shape == x.shape and residual.dtype == x.dtype
                             and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)))
-        ctx.cfg = (relu_mode | clip, residual is not None, group, count)
-        _BNFn.last = None if clip else _BnSrc(x, coef, relu_mode, mask)
+        ctx.cfg = (relu_mode | clip | (act << 4), residual is not None, group, count)
+        _BNFn.last = None if (clip or act) else _BnSrc(x, coef, relu_mode, mask)
         return y
 
     @staticmethod
@@ -1144,7 +1151,9 @@ class _BNEvalFn(torch.autograd.Function):
 
 
 def _act_code(relu) -> int:
-    """False / True / 6 -> 0 (none), 1 (ReLU), 6 (ReLU6)."""
+    """False / True / 6 -> 0 (none), 1 (ReLU), 6 (ReLU6); "silu", "hardswish", ... -> ACT_CODES << 4."""
+    if isinstance(relu, str):
+        return ACT_CODES[relu] << 4
     return 6 if (relu is not True and relu == 6) else (1 if relu else 0)
 
 
@@ -1172,6 +1181,9 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
         if not relu and residual is None:
             y._dpa_bn_plain = True      # activation-free BN output: as a residual its gradient may arrive unmasked + bit mask
         return y
+    if isinstance(relu, str):          # eval mode is not a hot path: BN from running statistics, then the activation kernel
+        y = _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), 0)
+        return activation(y, relu)
     return _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), _act_code(relu))
 
 

@@ -588,6 +588,40 @@ def test_depthwise_direct_equals_block_diagonal_path():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["silu", "hardswish", "gelu"])
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_smooth_activation(dtype, kind, training):
+    """BN + SiLU / hard-swish / GELU in one normalise pass; backward folds the activation's slope (at the recomputed
+    pre-activation) into the BN reduce and apply kernels.  Reference: BN then the activation in fp32 autograd."""
+    torch.manual_seed(4)
+    N, H, W, C = 4, 7, 9, 96
+    fn = {"silu": TF.silu, "hardswish": TF.hardswish, "gelu": TF.gelu}[kind]
+    x = (torch.randn(N, H, W, C, device=DEV) * 2 + 0.5).to(dtype).requires_grad_(True)
+    g = (torch.rand(C, device=DEV) * 2 + 1).requires_grad_(True)
+    b = torch.randn(C, device=DEV).requires_grad_(True)
+    rm, rv = torch.randn(C, device=DEV) * 0.1 + 0.5, torch.rand(C, device=DEV) + 3.5
+    rm2, rv2 = rm.clone(), rv.clone()
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    y = F.batch_norm(x, g, b, rm, rv, nbt if training else None, training, 0.1, 1e-5, relu=kind)
+    gy = torch.randn_like(y.float()).to(dtype)
+    y.backward(gy)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = fn(TF.batch_norm(xr, rm2, rv2, gr, br, training, 0.1, 1e-5))
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, dtype, what="y")
+    if training or dtype == torch.float32 or kind != "hardswish":
+        # (eval mode applies the activation to the ROUNDED BN output; hard-swish's slope jumps at +-3, so a bf16
+        # value that rounds across the kink legitimately gets the other slope)
+        _close(x.grad.permute(0, 3, 1, 2), xr.grad, dtype, scale=2.0, what="dx")
+    if training:                 # eval-mode BN is frozen: no parameter gradients
+        _close(g.grad, gr.grad, dtype, scale=4.0, what="dgamma")
+        _close(b.grad, br.grad, dtype, scale=4.0, what="dbeta")
+        _close(rm, rm2, torch.float32, what="running_mean")
+        _close(rv, rv2, torch.float32, what="running_var")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("res", [False, True])
 @pytest.mark.parametrize("training", [True, False])
 def test_batch_norm_relu6(dtype, res, training):
