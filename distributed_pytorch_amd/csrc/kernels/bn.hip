@@ -792,7 +792,8 @@ static void fold_finalize_launch(int mode, BnFinalizeArgs a, hipStream_t s) {
   a.chunk = (a.nparts + a.nchunk - 1) / a.nchunk;
   if (a.nchunk > 1 && (a.tmp == nullptr || a.counter == nullptr))
     throw std::invalid_argument("bn_fold_finalize: scratch slab and ticket counters required");
-  if (ceil_div(a.C, 64) > 64) throw std::invalid_argument("bn_fold_finalize: more than 4096 channels");
+  // one ticket counter per 64-channel group; callers allocate 256 of them (hip_ops._bn_scratch)
+  if (ceil_div(a.C, 64) > 256) throw std::invalid_argument("bn_fold_finalize: more than 16384 channels");
   dim3 grid(ceil_div(a.C, 64), a.nchunk);
   if (mode == 0) hipLaunchKernelGGL(bn_fold_finalize_kernel<0>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(bn_fold_finalize_kernel<1>, grid, dim3(256), 0, s, a);

@@ -820,7 +820,7 @@ def _bn_scratch(nparts: int, C_: int, device):
     once; every launch leaves them zeroed.  BatchNorm kernels of one device run on one stream."""
     t = _bn_tickets.get(device.index)
     if t is None:
-        t = torch.zeros(64, dtype=torch.int32, device=device)
+        t = torch.zeros(256, dtype=torch.int32, device=device)      # one per 64-channel group: C <= 16384
         _bn_tickets[device.index] = t
     n = C().bn_fold_chunks(nparts)
     tmp = torch.empty((n, 2, C_), dtype=torch.float64, device=device) if n > 1 else None
