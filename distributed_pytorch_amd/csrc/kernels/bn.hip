@@ -193,16 +193,41 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = b - rm[c] * g * is;
 }
 
-__global__ void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, float* o1, float* o2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// [nparts][2][C] -> o1[C], o2[C].  16 channel lanes x 16 part lanes per workgroup, four rows in flight per lane, the part
+// lanes meet in LDS in a fixed order.  (One thread per channel walking 1024 rows serially took 200 us per bias
+// gradient -- 30 % of a ConvNeXt step.)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, float* o1,
+                                                           float* o2) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nparts; ++k) {
-    s1 += (double)partial[((size_t)k * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)k * 2 + 1) * C + c];
+  if (c < C) {
+    int k = pl;
+    for (; k + 48 < nparts; k += 64) {
+      const float a0 = partial[((size_t)k * 2 + 0) * C + c], b0 = partial[((size_t)k * 2 + 1) * C + c];
+      const float a1 = partial[((size_t)(k + 16) * 2 + 0) * C + c], b1 = partial[((size_t)(k + 16) * 2 + 1) * C + c];
+      const float a2 = partial[((size_t)(k + 32) * 2 + 0) * C + c], b2 = partial[((size_t)(k + 32) * 2 + 1) * C + c];
+      const float a3 = partial[((size_t)(k + 48) * 2 + 0) * C + c], b3 = partial[((size_t)(k + 48) * 2 + 1) * C + c];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; k < nparts; k += 16) {
+      s1 += (double)partial[((size_t)k * 2 + 0) * C + c];
+      s2 += (double)partial[((size_t)k * 2 + 1) * C + c];
+    }
   }
-  o1[c] = (float)s1;
-  o2[c] = (float)s2;
+  red[0][pl][cl] = s1;
+  red[1][pl][cl] = s2;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int q = 0; q < 16; ++q) {
+    t1 += red[0][q][cl];
+    t2 += red[1][q][cl];
+  }
+  o1[c] = (float)t1;
+  o2[c] = (float)t2;
 }
 
 // [nparts][2][C] -> [nout][2][C]: block (cx, j) folds parts [j*chunk, (j+1)*chunk) of 64 channels,
@@ -703,7 +728,7 @@ void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* r
 void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
                             hipStream_t s) {
   // partial[.][0] = sum dy (dbeta), partial[.][1] = sum dy*xhat (dgamma)
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partial, nparts, C, dbeta,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, s, partial, nparts, C, dbeta,
                      dgamma);
   DPA_CHECK_HIP(hipGetLastError());
 }

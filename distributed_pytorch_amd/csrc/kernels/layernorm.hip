@@ -13,7 +13,7 @@
 namespace dpa {
 namespace {
 
-constexpr int kLnMaxBlocks = 1024;
+constexpr int kLnMaxBlocks = 512;
 
 __device__ __forceinline__ float group_sum(float v, int G) {
   for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -171,16 +171,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   for (int c = threadIdx.x; c < 2 * C; c += 256) partial[(size_t)blockIdx.x * 2 * C + c] = red[c];
 }
 
-// out[which][c] = sum over partial rows, fixed order; which 0 -> dgamma, 1 -> dbeta
+// out[which][c] = sum over partial rows (which 0 -> dgamma, 1 -> dbeta).  16 column lanes x 16 part lanes per workgroup,
+// four rows in flight per lane, fixed order.
 __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ partial, int nparts, int C,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float beta_w,
                                                       float beta_b) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * C) return;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;          // column of the [2*C] row
   float a = 0.f;
-  for (int p = 0; p < nparts; ++p) a += partial[(size_t)p * 2 * C + c];
-  if (c < C) dgamma[c] = beta_w == 0.f ? a : a + beta_w * dgamma[c];
-  else dbeta[c - C] = beta_b == 0.f ? a : a + beta_b * dbeta[c - C];
+  if (c < 2 * C) {
+    int p = pl;
+    for (; p + 48 < nparts; p += 64) {
+      const float v0 = partial[(size_t)p * 2 * C + c], v1 = partial[(size_t)(p + 16) * 2 * C + c];
+      const float v2 = partial[(size_t)(p + 32) * 2 * C + c], v3 = partial[(size_t)(p + 48) * 2 * C + c];
+      a += (v0 + v1) + (v2 + v3);
+    }
+    for (; p < nparts; p += 16) a += partial[(size_t)p * 2 * C + c];
+  }
+  red[pl][cl] = a;
+  __syncthreads();
+  if (pl != 0 || c >= 2 * C) return;
+  float t = 0.f;
+  for (int q = 0; q < 16; ++q) t += red[q][cl];
+  if (c < C) dgamma[c] = beta_w == 0.f ? t : t + beta_w * dgamma[c];
+  else dbeta[c - C] = beta_b == 0.f ? t : t + beta_b * dbeta[c - C];
 }
 
 struct LnPlan {
@@ -238,7 +253,7 @@ void ln_bwd_launch(const void* dy, const void* x, const float* w, const float* m
   else if (p.maxch == 2) { DPA_LN_BWD(2); }
   else { DPA_LN_BWD(4); }
 #undef DPA_LN_BWD
-  hipLaunchKernelGGL(ln_fold_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, s, partial, p.blocks, C, dgamma, dbeta,
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, s, partial, p.blocks, C, dgamma, dbeta,
                      beta_w, beta_b);
   DPA_CHECK_HIP(hipGetLastError());
 }
