@@ -120,10 +120,12 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 }
 
 // ---- smooth activations: 1 sigmoid, 2 SiLU, 3 hard-sigmoid, 4 hard-swish, 5 GELU (erf) -------------------------
+// sigmoid through v_rcp_f32 (1 ulp): the IEEE division costs more VALU than the rest of the activation together
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float act_value(int act, float x) {
   switch (act) {
-    case 1: return 1.f / (1.f + __expf(-x));
-    case 2: return x / (1.f + __expf(-x));
+    case 1: return fast_sigmoid(x);
+    case 2: return x * fast_sigmoid(x);
     case 3: return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
     case 5: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
     default: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
@@ -131,8 +133,8 @@ __device__ __forceinline__ float act_value(int act, float x) {
 }
 __device__ __forceinline__ float act_slope(int act, float x) {
   switch (act) {
-    case 1: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
-    case 2: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case 1: { const float s = fast_sigmoid(x); return s * (1.f - s); }
+    case 2: { const float s = fast_sigmoid(x); return s * (1.f + x * (1.f - s)); }
     case 3: return (x > -3.f && x < 3.f) ? (1.f / 6.f) : 0.f;
     case 5: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
     default: return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f));   // ATen's convention at +-3
