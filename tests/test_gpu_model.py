@@ -252,3 +252,35 @@ def test_lazy_residual_gradient_equals_materialised(arch):
     assert torch.equal(o1, o2) and l1 == l2
     for n in g1:
         assert torch.allclose(g1[n], g2[n], rtol=1e-5, atol=1e-7), n
+
+
+@pytest.mark.parametrize("arch", ["regnet_y_128gf", "efficientnet_b7", "convnext_large", "densenet201", "resnext101_64x4d",
+                                  "vgg19_bn", "wide_resnet101_2", "regnet_x_32gf"])
+def test_largest_zoo_members_take_a_bf16_training_step(arch):
+    """The widest / deepest member of each family (7392-channel BatchNorms, 644 M parameters, 2560-wide depthwise
+    convolutions ...) runs one AMP O2 step and an eval forward: kernel limits are sized for the whole registry."""
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.ops import functional as F
+    from distributed_pytorch_amd.optim import FusedSGD
+
+    amp.state().reset()
+    torch.manual_seed(0)
+    try:
+        m = models.create_model(arch).cuda().train()
+        opt = FusedSGD(m.parameters(), lr=0.001, momentum=0.9, weight_decay=1e-4)
+        m, opt = amp.initialize(m, opt, opt_level="O2", dtype="bf16")
+        x = torch.randint(0, 256, (4, 224, 224, 3), dtype=torch.uint8, device="cuda")
+        t = torch.randint(0, 1000, (4,), device="cuda")
+        loss, _ = F.loss_and_metrics(m(x), t)
+        opt.zero_grad()
+        with amp.scale_loss(loss, opt) as s:
+            s.backward()
+        opt.step()
+        assert torch.isfinite(loss) and float(loss) < 50
+        m.eval()
+        with torch.no_grad():
+            out = m(x)
+        assert out.shape == (4, 1000) and torch.isfinite(out.float()).all()
+    finally:
+        amp.state().reset()
+        torch.cuda.empty_cache()
