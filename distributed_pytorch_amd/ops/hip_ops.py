@@ -319,7 +319,8 @@ class _ConvFn(torch.autograd.Function):
         if bnsrc is not None:
             bnsrc.uses += 1
             if _FUSE_BN_BWD and x is x_in and (sh, sw) == (1, 1) and Cx == Cw and x.dtype != torch.float32 \
-                    and bnsrc.x.shape == x.shape and bnsrc.x.dtype == x.dtype:
+                    and bnsrc.x.shape == x.shape and bnsrc.x.dtype == x.dtype \
+                    and _FUSE_BN_BWD_MIN <= x.numel() * x.element_size() <= _FUSE_BN_BWD_MAX:
                 ctx.bnsrc = bnsrc
         ctx.save_for_backward(x, weight, y if relu else None)
         # no zero tensors for the outputs nobody differentiates (the statistics slab is up to 51 MB per layer)
@@ -410,6 +411,9 @@ def join_side_stream() -> None:
 
 
 _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") == "1"
+# size window (MiB of the BN input) inside which the fusion is taken -- tuning hook
+_FUSE_BN_BWD_MIN = int(float(os.environ.get("DPA_FUSE_BN_BWD_MIN_MB", "0")) * 2 ** 20)
+_FUSE_BN_BWD_MAX = int(float(os.environ.get("DPA_FUSE_BN_BWD_MAX_MB", "1e9")) * 2 ** 20)
 # data_ptr of a freshly produced data gradient -> (partial slab, data_ptr of the BN input it was reduced
 # against, tensor version).  BatchNorm backward uses the slab only if the gradient it receives is that very
 # tensor, unmodified: autograd sums gradients of a multiply-used tensor either out of place (new data_ptr)
