@@ -35,6 +35,21 @@ class GraphedTrainStep:
         self.key = None
         self._seen_key, self._seen = None, 0
         self.replays = 0
+        self.stream = None          # warm-up AND capture run on this side stream (see _on_side_stream)
+
+    def _on_side_stream(self, images, target):
+        """An eager warm-up step on the capture stream.  Autograd remembers the stream a node was created on; a
+        parameter whose gradient arrives through AccumulateGrad (squeeze-excitation weights, layer scales) would
+        otherwise make the engine synchronise the capturing stream with the stream of the warm-up steps -- a
+        cross-stream wait that is illegal during capture (hipStreamEndCapture faulted on it)."""
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(images.device)
+        cur = torch.cuda.current_stream(images.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._step(images, target)
+        cur.wait_stream(self.stream)
+        return out
 
     # the eager step, also what gets captured
     def _step(self, images, target):
@@ -58,7 +73,9 @@ class GraphedTrainStep:
             sync()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(images.device)
+        with torch.cuda.graph(g, stream=self.stream):
             loss, rec = self._step(self.static_x, self.static_t)
         self.graph, self.loss, self.rec = g, loss, rec
         self.key = self._key(images, target)
@@ -77,7 +94,7 @@ class GraphedTrainStep:
                 self._seen_key, self._seen = key, 0
             self._seen += 1
             if self._seen <= self.warmup:
-                return self._step(images, target)
+                return self._on_side_stream(images, target)
             try:
                 self._capture(images, target)
             except Exception as exc:  # noqa: BLE001
