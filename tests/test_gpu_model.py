@@ -149,7 +149,8 @@ def test_fp16_dynamic_loss_scaling_trains_and_recovers_from_overflow():
     amp.state().reset()
 
 
-def test_syncbn_gpu_path_equals_plain_bn_on_one_rank():
+@pytest.mark.parametrize("act", [True, "silu", 6])
+def test_syncbn_gpu_path_equals_plain_bn_on_one_rank(act):
     """The SyncBN branch (packed [sum, sumsq, n] all-reduce, device-side count, separate coefficient
     kernel) must reproduce plain BN when the group has a single rank."""
     from distributed_pytorch_amd.ops import functional as F, hip_ops
@@ -167,7 +168,7 @@ def test_syncbn_gpu_path_equals_plain_bn_on_one_rank():
         try:
             rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
             nbt = torch.zeros((), dtype=torch.long, device="cuda")
-            y = F.batch_norm(xs[i], ws[i], bs[i], rm, rv, nbt, True, 0.1, 1e-5, relu=True, group=group)
+            y = F.batch_norm(xs[i], ws[i], bs[i], rm, rv, nbt, True, 0.1, 1e-5, relu=act, group=group)
             y.float().square().sum().backward()
             outs.append(y.detach().float())
             stats.append((rm, rv))
