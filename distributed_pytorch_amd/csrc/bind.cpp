@@ -298,9 +298,12 @@ PYBIND11_MODULE(_C, m) {
   m.def("act_bwd", [](uintptr_t x, uintptr_t dy, uintptr_t dx, long n, int act, int dtype, uintptr_t s) {
     act_bwd_launch(ptr<const void>(x), ptr<const void>(dy), ptr<void>(dx), n, act, dtype, st(s));
   });
-  m.def("se_scale_fwd", [](uintptr_t x, uintptr_t sc, uintptr_t y, long NB, int HW, int C, int dtype, uintptr_t s) {
-    se_scale_fwd_launch(ptr<const void>(x), ptr<const float>(sc), ptr<void>(y), NB, HW, C, dtype, st(s));
-  });
+  m.def("se_scale_fwd", [](uintptr_t x, uintptr_t sc, uintptr_t y, long NB, int HW, int C, int dtype, uintptr_t s,
+                           uintptr_t add) {
+    se_scale_fwd_launch(ptr<const void>(x), ptr<const float>(sc), ptr<void>(y), NB, HW, C, dtype, st(s),
+                        ptr<const float>(add));
+  }, py::arg("x"), py::arg("sc"), py::arg("y"), py::arg("NB"), py::arg("HW"), py::arg("C"), py::arg("dtype"),
+     py::arg("stream"), py::arg("add") = 0);
   m.def("se_scale_bwd", [](uintptr_t dy, uintptr_t x, uintptr_t sc, uintptr_t dx, uintptr_t ds, long NB, int HW, int C,
                            int dtype, uintptr_t s) {
     se_scale_bwd_launch(ptr<const void>(dy), ptr<const void>(x), ptr<const float>(sc), ptr<void>(dx), ptr<float>(ds), NB,

@@ -192,7 +192,8 @@ void act_launch_t(const void* x, const void* dy, void* out, long n, int act, hip
 // y[n][p][c] = x[n][p][c] * s[n][c]                                         (s fp32 [N][C])
 template <typename T>
 __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, const float* __restrict__ s,
-                                                       T* __restrict__ y, long total, int HW, int chunks) {
+                                                       T* __restrict__ y, long total, int HW, int chunks,
+                                                       const float* __restrict__ add) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -202,8 +203,14 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, 
     const float* sp = s + n * (long)chunks * VEC + ch * VEC;
     Vec16<T> v, o;
     v.load(x + i * VEC);
+    if (add != nullptr) {            // y = x * s[n][c] + add[n][c] (the SE block's dx: dy * gate + d(mean) / HW)
+      const float* ap = add + n * (long)chunks * VEC + ch * VEC;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * sp[j]);
+      for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * sp[j] + ap[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * sp[j]);
+    }
     o.store(y + i * VEC);
   }
 }
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void se_scale_bwd_kernel(const T* __restrict__
         acc[j] += gj * v.get(j);
         o.set(j, gj * sv[j]);
       }
-      o.store(dx + off);
+      if (dx != nullptr) o.store(dx + off);
     }
   }
 #pragma unroll
@@ -409,13 +416,14 @@ void act_bwd_launch(const void* x, const void* dy, void* dx, long n, int act, in
   DPA_DISPATCH_DTYPE(dtype, (act_launch_t<T, true>(x, dy, dx, n, act, s)));
 }
 
-void se_scale_fwd_launch(const void* x, const float* sc, void* y, long NB, int HW, int C, int dtype, hipStream_t s) {
+void se_scale_fwd_launch(const void* x, const float* sc, void* y, long NB, int HW, int C, int dtype, hipStream_t s,
+                         const float* add) {
   const int vec = dtype == kF32 ? 4 : 8;
   if (C % vec != 0) throw std::invalid_argument("se_scale: C must fill 16-byte vectors");
   const long total = NB * HW * (C / vec);
   if (total <= 0) return;
   DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(se_scale_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, sc,
-                                               (T*)y, total, HW, C / vec));
+                                               (T*)y, total, HW, C / vec, add));
   DPA_CHECK_HIP(hipGetLastError());
 }
 void se_scale_bwd_launch(const void* dy, const void* x, const float* sc, void* dx, float* ds, long NB, int HW, int C,

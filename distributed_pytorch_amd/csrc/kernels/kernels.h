@@ -196,7 +196,8 @@ void add_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hi
 void act_fwd_launch(const void* x, void* y, long n, int act, int dtype, hipStream_t s);
 void act_bwd_launch(const void* x, const void* dy, void* dx, long n, int act, int dtype, hipStream_t s);
 // y[n][p][c] = x[n][p][c] * sc[n][c] (squeeze-excitation gate / stochastic depth); backward: dx and ds = sum_p dy * x
-void se_scale_fwd_launch(const void* x, const float* sc, void* y, long NB, int HW, int C, int dtype, hipStream_t s);
+void se_scale_fwd_launch(const void* x, const float* sc, void* y, long NB, int HW, int C, int dtype, hipStream_t s,
+                         const float* add = nullptr);   // y = x * sc[n][c] (+ add[n][c]); se_scale_bwd: dx may be null
 void se_scale_bwd_launch(const void* dy, const void* x, const float* sc, void* dx, float* ds, long NB, int HW, int C,
                          int dtype, hipStream_t s);
 // counter (device, optional): RNG stream position read by the kernel and advanced by n afterwards

@@ -176,8 +176,9 @@ class SqueezeExcitation(nn.Module):
     """torchvision ``SqueezeExcitation``: ``x * gate(fc2(act(fc1(mean_hw(x)))))`` with 1x1-conv shaped parameters
     (``fc1.weight [S, C, 1, 1]`` ...) so checkpoints interchange.
 
-    The activation-sized work -- the H*W mean, the gate multiply and its backward (``dx`` and the per-(sample, channel)
-    reduction of ``dy * x`` in one pass) -- runs in HIP kernels; the excitation MLP is two ``[N, C] x [C, S]`` fp32
+    On the GPU the whole block is one autograd node (``hip_ops._SEBlockFn``): the activation-sized work -- the H*W
+    mean, the gate multiply, the backward reduction of ``dy * x`` and ``dx = dy * s + d(mean) / HW`` in one pass -- runs
+    in HIP kernels; the excitation MLP is two ``[N, C] x [C, S]`` fp32
     products on a tensor 1/(H*W) the size of the activation and goes to the BLAS library through ``torch.addmm``
     (squeeze widths such as 12 or 26 do not fill an MFMA tile, and at N x C elements the layer is launch latency,
     not math)."""
@@ -202,6 +203,8 @@ class SqueezeExcitation(nn.Module):
         return torch.sigmoid(s) if self._gate == "sigmoid" else torch.nn.functional.hardsigmoid(s)
 
     def forward(self, x):
+        if F._on_gpu(x) and F.se_fused():
+            return F.se_block(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self._act, self._gate)
         return F.se_scale(x, self.gate(x))
 
 

@@ -236,6 +236,16 @@ def se_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return x * s.to(x.dtype).view(s.shape[0], 1, 1, s.shape[1])
 
 
+def se_fused() -> bool:
+    return _hip()._SE_FUSED
+
+
+def se_block(x, w1, b1, w2, b2, act: str, gate: str) -> torch.Tensor:
+    """GPU only: the whole squeeze-excitation block as one autograd node (see ``hip_ops._SEBlockFn``); ``w1`` / ``w2``
+    are the 1x1-conv shaped parameters of ``nn.SqueezeExcitation``."""
+    return _hip().se_block(x, w1, b1, w2, b2, act, gate)
+
+
 def stochastic_depth(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
     """torchvision ``StochasticDepth(p, "row")``: drops the whole residual branch of a sample with probability
     ``p`` and rescales the survivors by ``1 / (1 - p)``."""

@@ -390,6 +390,42 @@ def test_layer_norm_and_gelu(dtype, rows, C):
     _close(x.grad, xr.grad, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act,gate", [("relu", "sigmoid"), ("silu", "sigmoid"), ("relu", "hardsigmoid")])
+@pytest.mark.parametrize("fused", [True, False])
+def test_squeeze_excitation_block(dtype, act, gate, fused):
+    """nn.SqueezeExcitation on the GPU -- as one autograd node (fused backward: ds reduction, MLP backward, then
+    dx = dy * s + d(mean) / HW in one pass) and as separate nodes -- against the CPU module in fp32."""
+    import copy
+
+    from distributed_pytorch_amd import nn as dnn
+    from distributed_pytorch_amd.ops import hip_ops
+
+    torch.manual_seed(12)
+    ref = dnn.SqueezeExcitation(48, 12, activation=act, scale_activation=gate)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(3.0)                            # gates away from 0.5, hard-sigmoid partly saturated
+    gpu = copy.deepcopy(ref).cuda()
+    x0 = torch.randn(3, 6, 5, 48)
+    g0 = torch.randn(3, 6, 5, 48)
+    xr = x0.to(dtype).float().clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g0.to(dtype).float())
+    x = x0.to(dtype).cuda().requires_grad_(True)
+    try:
+        hip_ops._SE_FUSED = fused
+        y = gpu(x)
+        y.backward(g0.to(dtype).cuda())
+    finally:
+        hip_ops._SE_FUSED = True
+    _close(y, yr, dtype, what="y")
+    _close(x.grad, xr.grad, dtype, scale=2.0, what="dx")
+    for (n, a), (_, b) in zip(gpu.named_parameters(), ref.named_parameters()):
+        assert a.grad is not None and a.grad.shape == a.shape, n
+        _close(a.grad, b.grad, dtype, scale=4.0, what=n)
+
+
 @pytest.mark.parametrize("lp", [None, torch.bfloat16])
 def test_fused_sgd_matches_torch(lp):
     from distributed_pytorch_amd.optim import FusedSGD
