@@ -526,6 +526,10 @@ void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, in
   if (two_windows(kh, kw, sh, sw)) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 2>), dim3(grid_for(total)), dim3(256), 0, s,
                                                  idx, (const T*)dy, (T*)dx, g, total));
+  } else if (kh <= 3 * sh && kw <= 3 * sw) {
+    // 3x3 stride 1 (the pooling branch of every Inception block): nine candidate windows, all loaded up front
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 3>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 idx, (const T*)dy, (T*)dx, g, total));
   } else {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 0>), dim3(grid_for(total)), dim3(256), 0, s,
                                                  idx, (const T*)dy, (T*)dx, g, total));
