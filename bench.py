@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """Headline benchmark: ResNet-50 mixed-precision (bf16) training throughput, images/sec, whole job.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps 20 --warmup 5          # starts N ranks itself (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; gradients are all-reduced by the native bucketed RCCL reducer overlapped with
-backward.  Every timed step does the full training iteration of the reference's AMP script
+Like the reference (``mp.spawn(main_worker, nprocs=ngpus)``, imagenet_ddp.py:76-85) the plain command launches
+its own workers: fresh spawn-context children started before the parent touches a GPU, supervised, and the
+command fails fast when the node has fewer than N devices.  Under torchrun the ranks are taken from the
+environment.  Gradients are all-reduced by the native C++ bucketed reducer calling RCCL directly, overlapped
+with backward; the rendezvous is the native TcpStore -- ``torch.distributed`` is not initialised, so each rank
+owns exactly ONE RCCL communicator (``--dist-backend nccl`` switches to torch's process group).
+
+Every timed step does the full training iteration of the reference's AMP script
 (imagenet_ddp_apex.py:367-425): async H2D of a fresh uint8 batch from pinned memory + on-GPU
 normalise (prefetcher), forward, loss, zero_grad, backward (+all-reduce), fused SGD step.
 Synthetic data, random-init weights (no network / datasets on the benchmark machines).
@@ -18,12 +24,10 @@ import os
 import sys
 import time
 
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -31,58 +35,115 @@ def main():
     # BASELINE.json north star: "per-GPU batch is sized to use the 288 GB HBM".  Measured on one MI355X (bf16):
     # 256 -> 9.46k, 512 -> 10.27k, 1024 -> 10.74k, 2048 -> 10.96k img/s (41 GB at 1024); the reference's 224 was a
     # 16 GB-GPU limit (imagenet_ddp_apex.py:63-67).  LR follows the reference's 0.1 * global_batch / 256 rule.
-    ap.add_argument("--batch-size", type=int, default=1024, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch-size", type=int, default=None, help="per-GPU batch (weak scaling); default 1024")
     ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--num-classes", type=int, default=1000)
     ap.add_argument("--bucket-mb", type=float, default=None)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("DPA_BENCH_GRAPH", "0")))
     ap.add_argument("--force-ddp", action="store_true",
                     help="1-GPU rehearsal of the multi-GPU path: process group of one rank + DDP wrapper + RCCL reducer")
-    args = ap.parse_args()
+    ap.add_argument("--dist-backend", default=os.environ.get("DPA_BENCH_BACKEND", "native"),
+                    help="native (TcpStore + C++ RCCL communicator, default) | nccl (torch.distributed) | gloo")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu = rehearsal of the launch / rendezvous / reducer logic without a GPU (tests)")
+    args = ap.parse_args(argv)
+    if args.batch_size is None:
+        args.batch_size = 1024 if args.device == "cuda" else 8
+    if args.dtype is None:
+        args.dtype = "bf16" if args.device == "cuda" else "fp32"
+    return args
 
-    import torch.distributed as dist
 
-    import distributed_pytorch_amd as dpa
-    from distributed_pytorch_amd import amp, models
+def _spawned_rank(local_rank, args):
+    os.environ["RANK"] = str(local_rank)
+    run(args)
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks here."""
+    from distributed_pytorch_amd import launch
+
+    have = launch.device_count() if args.device == "cuda" else int(os.environ.get("DPA_NPROC_PER_NODE", args.gpus))
+    if have < args.gpus:
+        print("bench.py: --gpus %d requested but this node has %d GPU(s)" % (args.gpus, have), file=sys.stderr)
+        return 2
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(launch.free_port())
+    os.environ["WORLD_SIZE"] = str(args.gpus)
+    try:
+        launch.spawn(_spawned_rank, args.gpus, (args,))
+    except launch.ProcessFailure as exc:
+        print("bench.py: %s" % exc, file=sys.stderr)
+        return 1
+    return 0
+
+
+def run(args) -> None:
+    import torch
+
+    from distributed_pytorch_amd import amp, launch, models
     from distributed_pytorch_amd.data.datasets import SyntheticImageNet
     from distributed_pytorch_amd.data.prefetcher import StreamPrefetcher
     from distributed_pytorch_amd.ops import functional as F
     from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.parallel import process_group as pg
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    # the input copy stream is created first so it gets a hardware queue of its own (see data.prefetcher.copy_stream)
-    from distributed_pytorch_amd.data.prefetcher import copy_stream as _copy_stream
+    use_gpu = args.device == "cuda"
+    copy_stream = None
+    if use_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible"
+                             % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        # the input copy stream is created first so it gets a hardware queue of its own (see data.prefetcher.copy_stream)
+        from distributed_pytorch_amd.data.prefetcher import copy_stream as _copy_stream
 
-    copy_stream = _copy_stream(device) if os.environ.get("DPA_EARLY_COPY_STREAM", "1") == "1" else torch.cuda.Stream(device)
+        copy_stream = _copy_stream(device) if os.environ.get("DPA_EARLY_COPY_STREAM", "1") == "1" \
+            else torch.cuda.Stream(device)
+    else:
+        device = torch.device("cpu")
+    cpus = launch.set_affinity_from_env(use_gpu=use_gpu) if world > 1 else []
+
     ddp = world > 1 or args.force_ddp
+    backend = None
     if ddp:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
             os.environ["DPA_FORCE_NATIVE_REDUCER"] = "1"      # a single rank would otherwise skip the reducer
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank,
-                                device_id=device)
+        backend = args.dist_backend
+        timeout_s = float(os.environ.get("DPA_DIST_TIMEOUT_S", "300"))
+        try:
+            pg.init_process_group(backend, "env://", world, rank, timeout_s=timeout_s, use_gpu=use_gpu)
+        except RuntimeError as exc:
+            # every rank learns of a failed native communicator through the store (process_group.py), so all of
+            # them arrive here together and fall back to torch's process group
+            if backend not in pg.NATIVE_NAMES or "native RCCL communicator" not in str(exc):
+                raise
+            if rank == 0:
+                print("bench.py: %s -- falling back to torch.distributed" % exc, file=sys.stderr)
+            pg.destroy_process_group()
+            backend = "nccl"
+            pg.init_process_group(backend, "env://", world, rank, timeout_s=timeout_s, use_gpu=use_gpu)
 
     torch.manual_seed(1234)
-    model = models.create_model(args.arch).to(device)
+    model = models.create_model(args.arch, num_classes=args.num_classes).to(device)
     # reference recipe (imagenet_ddp_apex.py:162,527-543): peak lr = 0.1 * global_batch / 256 reached after a
     # 5-epoch linear warm-up; a benchmark of a few dozen steps sits at the start of that ramp (1 % of the peak),
     # which also keeps random-init / random-label training finite at global batches of 8k
     lr = 0.1 * args.batch_size * world / 256.0 * 0.01
-    if F._TORCH_BASELINE:   # stock PyTorch-ROCm reference point (MIOpen/rocBLAS/ATen + torch.optim.SGD)
-        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
-    else:
-        opt = FusedSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    opt = FusedSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
     if args.dtype == "fp32":
         model, opt = amp.initialize(model, opt, opt_level="O0")
     else:
@@ -96,20 +157,19 @@ def main():
 
         kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
         # Apex DDP (the reference's AMP script) does not re-broadcast BN buffers every forward
-        model = DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False, **kw)
+        model = DistributedDataParallel(model, device_ids=[local_rank] if use_gpu else None,
+                                        broadcast_buffers=False, **kw)
     model.train()
 
     total = args.steps + args.warmup + 2
     data = SyntheticImageNet(args.batch_size, world_size=world, rank=rank, image_size=args.image_size,
-                             steps=total)
+                             steps=total, num_classes=args.num_classes)
     base = getattr(model, "module", model)
-    pre = StreamPrefetcher(data, device, dtype=amp.compute_dtype(torch.float32),
-                           pad_c=0 if F._TORCH_BASELINE else 8,
-                           s2d=bool(getattr(base, "stem_s2d", False)) and not F._TORCH_BASELINE,
-                           stream=copy_stream)
+    pre = StreamPrefetcher(data, device, dtype=amp.compute_dtype(torch.float32), pad_c=8 if use_gpu else 0,
+                           s2d=bool(getattr(base, "stem_s2d", False)) and use_gpu, stream=copy_stream)
 
     graphed = None
-    if args.graph and world == 1 and not F._TORCH_BASELINE:
+    if args.graph and world == 1 and use_gpu:
         from distributed_pytorch_amd.utils.graph import GraphedTrainStep
 
         graphed = GraphedTrainStep(model, opt, warmup=2)
@@ -126,50 +186,74 @@ def main():
         opt.step()
         return loss
 
+    def fence():
+        if use_gpu:
+            torch.cuda.synchronize()
+        if ddp:
+            pg.barrier()
+        if use_gpu:
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         loss = step()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float32, device=device)
     if ddp:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pg.all_reduce_max(t)               # the slowest rank's wall time
     dt = float(t.item())
     final_loss = float(loss.item())
     if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
         final_loss = None               # keep the line strict JSON
-    ips = world * args.batch_size * args.steps / dt
+    n_ranks = pg.get_world_size() if ddp else 1       # what the communicator saw, not what the flag asked for
+    ips = n_ranks * args.batch_size * args.steps / dt
+    comm = None
+    if ddp:
+        comm = model.comm_summary()
+        comm["process_group"] = pg.get_backend()
+        raw = getattr(model.comm, "raw", None)
+        comm["rccl_ranks"] = int(raw.world_size) if raw is not None else None
+        if raw is not None:
+            from distributed_pytorch_amd import backend as _be
+
+            comm["rccl_version"] = int(_be.require().rccl_version())
+        comm["cpu_affinity"] = len(cpus)
     if rank == 0:
         print(json.dumps({
             "metric": "images/sec (whole job) %s %s training" % (
-                {"resnet50": "ResNet-50"}.get(args.arch, args.arch), "AMP" if args.dtype != "fp32" else "fp32") +
-                      (" [stock-PyTorch-ops baseline]" if F._TORCH_BASELINE else ""),
-            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                {"resnet50": "ResNet-50"}.get(args.arch, args.arch), "AMP" if args.dtype != "fp32" else "fp32"),
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": n_ranks if use_gpu else 0, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic uint8 %dx%d from pinned host memory, random-init weights" % (args.image_size, args.image_size),
             "final_loss": final_loss,
-            "config": {"model": args.arch, "global_batch": args.batch_size * world,
+            "config": {"model": args.arch, "global_batch": args.batch_size * n_ranks,
                        "per_gpu_batch": args.batch_size, "seq_len": None, "image_size": args.image_size,
-                       "parallelism": "dp%d" % world + (" (forced DDP path)" if args.force_ddp and world == 1 else ""),
+                       "parallelism": "dp%d" % n_ranks + (" (forced DDP path)" if args.force_ddp and world == 1 else ""),
+                       "ranks": n_ranks, "device": args.device,
                        "optimizer": "sgd+momentum+wd (fused)",
                        "amp": "O2 " + args.dtype if args.dtype != "fp32" else "O0",
                        "hip_graph": bool(graphed is not None and graphed.replays > 0),
-                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
+                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1) if use_gpu else None,
+                       "comm": comm},
         }), flush=True)
     if ddp:
-        dist.destroy_process_group()
+        pg.barrier()
+        pg.destroy_process_group()
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args)
+    run(args)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

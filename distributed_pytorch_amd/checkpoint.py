@@ -80,6 +80,10 @@ def save_checkpoint(state: Dict[str, Any], is_best: bool, out_dir: str = "",
                     filename: str = CHECKPOINT_NAME) -> str:
     """``torch.save`` + copy to ``model_best.pth.tar`` (reference
     ``nd_imagenet.py:356-359``; ``out_dir`` as in ``imagenet_ddp_apex.py:496-506``)."""
+    from .parallel import process_group as _pg
+
+    if _pg.is_initialized():
+        _pg.check_health()      # never persist weights / running statistics that a failed collective poisoned
     path = os.path.join(out_dir, filename) if out_dir else filename
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)

@@ -29,14 +29,24 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <tuple>
 #include <utility>
 #include <vector>
 
+#include "host_backend.h"
+#include "reducer_core.h"
+
 namespace py = pybind11;
+using dpa::comm::BucketReducerCore;
+using dpa::comm::HostBackend;
+using dpa::comm::OnTimeout;
+using dpa::comm::ReduceBackend;
+using dpa::comm::dtype_bytes;
 
 namespace {
 
@@ -110,15 +120,6 @@ ncclDataType_t nccl_dtype(int code) {  // dpa::DType codes
     default: throw std::invalid_argument("unsupported comm dtype");
   }
 }
-size_t dtype_bytes(int code) {
-  switch (code) {
-    case 0: return 4;
-    case 1: case 2: return 2;
-    case 3: return 8;
-    default: return 1;
-  }
-}
-
 class Communicator {
  public:
   Communicator(py::bytes id, int rank, int world, int device) : rank_(rank), world_(world), device_(device) {
@@ -129,9 +130,11 @@ class Communicator {
     CHECK_HIP(hipSetDevice(device));
     {
       py::gil_scoped_release nogil;
-      check_nccl(rccl().CommInitRank(&comm_, world, uid, rank), "ncclCommInitRank");
+      ncclComm_t c = nullptr;
+      check_nccl(rccl().CommInitRank(&c, world, uid, rank), "ncclCommInitRank");
+      comm_.store(c);
     }
-    // Normal priority on purpose.  A high-priority stream that event-waits on work of torch's default
+    // Normal priority by default.  A high-priority stream that event-waits on work of torch's default
     // (null) stream DEADLOCKED on MI355X / ROCm 7.0 runtime with GPU_MAX_HW_QUEUES=4 (both streams stay
     // busy forever, measured 2026-11: profiles/r1_notes.md); DPA_COMM_PRIORITY=1 opts back in.
     const char* prio = getenv("DPA_COMM_PRIORITY");
@@ -144,10 +147,8 @@ class Communicator {
     }
   }
   ~Communicator() {
-    if (comm_) {
-      if (aborted_) rccl().CommAbort(comm_);
-      else rccl().CommDestroy(comm_);
-    }
+    ncclComm_t c = comm_.exchange(nullptr);
+    if (c) rccl().CommDestroy(c);
     if (stream_) (void)hipStreamDestroy(stream_);
   }
   static py::bytes unique_id() {
@@ -161,27 +162,45 @@ class Communicator {
     return v;
   }
   hipStream_t pick(uintptr_t s) const { return s ? reinterpret_cast<hipStream_t>(s) : stream_; }
+  ncclComm_t live() const {
+    ncclComm_t c = comm_.load();
+    if (!c) throw std::runtime_error("RCCL communicator was aborted");
+    return c;
+  }
 
   void all_reduce(uintptr_t p, size_t count, int dtype, bool avg, uintptr_t s) {
     check_nccl(rccl().AllReduce(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), count, nccl_dtype(dtype),
-                                avg ? ncclAvg : ncclSum, comm_, pick(s)),
+                                avg ? ncclAvg : ncclSum, live(), pick(s)),
+               "ncclAllReduce");
+  }
+  void all_reduce_max(uintptr_t p, size_t count, int dtype, uintptr_t s) {
+    check_nccl(rccl().AllReduce(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), count, nccl_dtype(dtype),
+                                ncclMax, live(), pick(s)),
                "ncclAllReduce");
   }
   void broadcast(uintptr_t p, size_t nbytes, int root, uintptr_t s) {
-    check_nccl(rccl().Broadcast(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), nbytes, ncclUint8, root, comm_,
+    check_nccl(rccl().Broadcast(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), nbytes, ncclUint8, root, live(),
                                 pick(s)),
                "ncclBroadcast");
   }
   void all_gather(uintptr_t send, uintptr_t recv, size_t count, int dtype, uintptr_t s) {
     check_nccl(rccl().AllGather(reinterpret_cast<void*>(send), reinterpret_cast<void*>(recv), count, nccl_dtype(dtype),
-                                comm_, pick(s)),
+                                live(), pick(s)),
                "ncclAllGather");
   }
-  void abort() { aborted_ = true; }
+  // ncclCommAbort: kernels of this communicator that are spinning on a dead peer exit, the streams drain.
+  // Callable from any thread (the reducer's watchdog); the communicator is unusable afterwards.
+  void abort() {
+    ncclComm_t c = comm_.exchange(nullptr);
+    if (c) rccl().CommAbort(c);
+  }
+  bool aborted() const { return comm_.load() == nullptr; }
   std::string async_error() {
+    ncclComm_t c = comm_.load();
+    if (!c) return "communicator aborted";
     ncclResult_t r = ncclSuccess;
-    rccl().CommGetAsyncError(comm_, &r);
-    return r == ncclSuccess ? std::string() : std::string(rccl().GetErrorString(r));
+    rccl().CommGetAsyncError(c, &r);
+    return (r == ncclSuccess || r == ncclInProgress) ? std::string() : std::string(rccl().GetErrorString(r));
   }
   // order `consumer` after everything enqueued so far on the comm stream (and vice versa)
   void comm_waits_for(uintptr_t producer) {
@@ -200,8 +219,8 @@ class Communicator {
   }
   int rank() const { return rank_; }
   int world() const { return world_; }
+  int device() const { return device_; }
   uintptr_t stream_handle() const { return reinterpret_cast<uintptr_t>(stream_); }
-  ncclComm_t raw() const { return comm_; }
   hipStream_t stream() const { return stream_; }
 
  private:
@@ -215,188 +234,92 @@ class Communicator {
     hipEvent_t e = events_[next_event_++ % events_.size()];
     return e;
   }
-  ncclComm_t comm_ = nullptr;
+  std::atomic<ncclComm_t> comm_{nullptr};
   hipStream_t stream_ = nullptr;
   int rank_, world_, device_;
-  bool aborted_ = false;
   std::vector<hipEvent_t> events_;
   size_t next_event_ = 0;
 };
 
-class BucketReducer {
+// The reducer's communication queue on a GPU: the communicator's HIP stream, HIP events as ready / done points,
+// one in-place ncclAllReduce(avg) per slice.  No host synchronisation anywhere -- the step stays asynchronous.
+class RcclBackend : public ReduceBackend {
  public:
-  struct Bucket {
-    uintptr_t ptr;
-    size_t count;
-    int dtype;
-    int nparams;
-    int pending;
-    bool launched;
-    hipEvent_t ready, done;
-  };
-  BucketReducer(std::shared_ptr<Communicator> comm, std::vector<uintptr_t> ptrs, std::vector<size_t> counts,
-                std::vector<int> dtypes, std::vector<int> param_bucket)
-      : comm_(std::move(comm)), param_bucket_(std::move(param_bucket)) {
-    if (ptrs.size() != counts.size() || ptrs.size() != dtypes.size()) throw std::invalid_argument("bucket arrays");
-    buckets_.resize(ptrs.size());
-    for (size_t b = 0; b < ptrs.size(); ++b) {
-      Bucket& k = buckets_[b];
-      k.ptr = ptrs[b]; k.count = counts[b]; k.dtype = dtypes[b]; k.nparams = 0; k.pending = 0; k.launched = false;
-      CHECK_HIP(hipEventCreateWithFlags(&k.ready, hipEventDisableTiming));
-      CHECK_HIP(hipEventCreateWithFlags(&k.done, hipEventDisableTiming));
-    }
-    for (int b : param_bucket_) {
-      if (b < 0 || b >= (int)buckets_.size()) throw std::invalid_argument("param -> bucket index out of range");
-      buckets_[b].nparams++;
-    }
-    prepare();
+  explicit RcclBackend(std::shared_ptr<Communicator> comm) : comm_(std::move(comm)) {}
+  ~RcclBackend() override {
+    for (hipEvent_t e : ready_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : done_) (void)hipEventDestroy(e);
   }
-  ~BucketReducer() {
-    for (Bucket& k : buckets_) {
-      (void)hipEventDestroy(k.ready);
-      (void)hipEventDestroy(k.done);
+  int world() const override { return comm_->world(); }
+  void resize(int n) override {
+    while ((int)ready_.size() < n) {
+      hipEvent_t r, d;
+      CHECK_HIP(hipEventCreateWithFlags(&r, hipEventDisableTiming));
+      CHECK_HIP(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+      ready_.push_back(r);
+      done_.push_back(d);
     }
   }
-  void prepare() {
-    for (Bucket& k : buckets_) {
-      k.pending = k.nparams;
-      k.launched = false;
+  void record_ready(int b, uintptr_t compute_stream) override {
+    CHECK_HIP(hipEventRecord(ready_.at(b), reinterpret_cast<hipStream_t>(compute_stream)));
+    CHECK_HIP(hipStreamWaitEvent(comm_->stream(), ready_.at(b), 0));
+  }
+  void launch(int, uintptr_t base, size_t offset_elems, size_t count, int dtype) override {
+    comm_->all_reduce(base + offset_elems * dtype_bytes(dtype), count, dtype, true, 0);
+  }
+  void record_done(int b) override { CHECK_HIP(hipEventRecord(done_.at(b), comm_->stream())); }
+  void wait_done(int b, uintptr_t compute_stream) override {
+    CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(compute_stream), done_.at(b), 0));
+  }
+  bool query_done(int b) override {
+    thread_local int bound_device = -1;
+    if (bound_device != comm_->device()) {
+      (void)hipSetDevice(comm_->device());
+      bound_device = comm_->device();
     }
-    next_ = 0;
-    launched_ = 0;
+    return hipEventQuery(done_.at(b)) != hipErrorNotReady;
   }
-  // gradient of parameter `idx` has been enqueued on `compute_stream`
-  void mark_ready(int idx, uintptr_t compute_stream) {
-    Bucket& k = buckets_.at(param_bucket_.at(idx));
-    if (k.pending <= 0) return;  // parameter used twice: already counted
-    if (--k.pending == 0) {
-      CHECK_HIP(hipEventRecord(k.ready, reinterpret_cast<hipStream_t>(compute_stream)));
-      flush(compute_stream, false);
-    }
-  }
-  // issue, in index order, every bucket whose gradients are complete (all of them when `force`)
-  void flush(uintptr_t compute_stream, bool force) {
-    while (next_ < buckets_.size()) {
-      Bucket& k = buckets_[next_];
-      if (k.pending > 0) {
-        if (!force) break;
-        k.pending = 0;  // unused parameters: their (zeroed) gradient slots are reduced as they are
-        CHECK_HIP(hipEventRecord(k.ready, reinterpret_cast<hipStream_t>(compute_stream)));
-      }
-      CHECK_HIP(hipStreamWaitEvent(comm_->stream(), k.ready, 0));
-      comm_->all_reduce(k.ptr, k.count, k.dtype, true, 0);
-      CHECK_HIP(hipEventRecord(k.done, comm_->stream()));
-      k.launched = true;
-      ++launched_;
-      ++next_;
-    }
-  }
-  // end of backward: issue the stragglers and make the compute stream wait for every bucket
-  void finalize(uintptr_t compute_stream) {
-    flush(compute_stream, true);
-    for (Bucket& k : buckets_) CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(compute_stream), k.done, 0));
-  }
-  int num_buckets() const { return (int)buckets_.size(); }
-  int launched() const { return launched_; }
+  std::string async_error() override { return comm_->aborted() ? std::string() : comm_->async_error(); }
+  void abort() override { comm_->abort(); }
 
  private:
   std::shared_ptr<Communicator> comm_;
-  std::vector<Bucket> buckets_;
-  std::vector<int> param_bucket_;
-  size_t next_ = 0;
-  int launched_ = 0;
+  std::vector<hipEvent_t> ready_, done_;
 };
 
+// Python handle of the reducer (either backend).  `stream` arguments are hipStream_t integers (0 on the host).
+class PyReducer {
+ public:
+  PyReducer(std::shared_ptr<ReduceBackend> backend, std::vector<uintptr_t> ptrs, std::vector<size_t> counts,
+            std::vector<int> dtypes, std::vector<int> param_bucket, size_t chunk_bytes, double timeout_s,
+            bool exit_on_timeout, double grace_s)
+      : core_(std::move(backend), std::move(ptrs), std::move(counts), std::move(dtypes), std::move(param_bucket),
+              chunk_bytes, timeout_s, exit_on_timeout ? OnTimeout::kExitProcess : OnTimeout::kFlagOnly, grace_s) {}
+  void prepare() { core_.prepare(); }
+  void mark_ready(int idx, uintptr_t s) { core_.mark_ready(idx, s); }
+  void flush(uintptr_t s, bool force) { core_.flush(s, force); }
+  void finalize(uintptr_t s) {
+    py::gil_scoped_release nogil;     // a host backend blocks here until its worker thread has retired the buckets
+    core_.finalize(s);
+  }
+  int num_buckets() const { return core_.num_buckets(); }
+  int launched() const { return core_.launched(); }
+  long collectives() const { return core_.collectives(); }
+  std::vector<int> observed_order() const { return core_.observed_order(); }
+  bool failed() const { return core_.failed(); }
+  std::string failure() const { return core_.failure(); }
 
-// ---- bucket planner (host logic of the reducer) ----------------------------------------------------
-// Packs parameters, given in expected gradient-ready order, into dtype-homogeneous flat buckets.  The first
-// bucket of each dtype is small (its all-reduce starts early), the parameters that become ready LAST form a
-// small bucket of their own (its all-reduce is the only one that cannot overlap with backward), everything
-// in between fills `cap_bytes` buckets sized for xGMI.  Every view offset is aligned to `align_bytes`.
-struct PlannedBucket {
-  long dtype_key = 0;
-  std::vector<long> pids, offsets;
-  long total = 0;     // elements, padded
+ private:
+  BucketReducerCore core_;
 };
-
-void plan_range(const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
-                const std::vector<long>& order, size_t begin, size_t end, long cap, long first_cap, long align,
-                std::vector<PlannedBucket>& out) {
-  std::vector<std::pair<long, int>> open;       // dtype -> index into out (few dtypes: linear search)
-  std::vector<long> first_done;
-  auto find_open = [&](long dk) -> int* {
-    for (auto& kv : open)
-      if (kv.first == dk) return &kv.second;
-    return nullptr;
-  };
-  auto done = [&](long dk) {
-    for (long d : first_done)
-      if (d == dk) return true;
-    return false;
-  };
-  for (size_t i = begin; i < end; ++i) {
-    const long pid = order[i];
-    const long dk = dkeys[pid], es = esz[pid], n = numels[pid];
-    int* cur = find_open(dk);
-    const long limit = done(dk) ? cap : first_cap;
-    if (cur != nullptr && *cur >= 0 && !out[*cur].pids.empty() && out[*cur].total * es + n * es > limit) {
-      if (!done(dk)) first_done.push_back(dk);
-      *cur = -1;
-    }
-    if (cur == nullptr) {
-      open.emplace_back(dk, -1);
-      cur = &open.back().second;
-    }
-    if (*cur < 0) {
-      out.emplace_back();
-      out.back().dtype_key = dk;
-      *cur = (int)out.size() - 1;
-    }
-    PlannedBucket& b = out[*cur];
-    b.pids.push_back(pid);
-    b.offsets.push_back(b.total);
-    const long align_el = std::max<long>(1, align / es);
-    b.total += (n + align_el - 1) / align_el * align_el;
-  }
-}
-
-std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> plan_buckets(
-    const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
-    const std::vector<long>& order, long cap, long first_cap, long align, long last_cap) {
-  if (numels.size() != esz.size() || numels.size() != dkeys.size())
-    throw std::invalid_argument("plan_buckets: per-parameter lists differ in length");
-  for (long pid : order)
-    if (pid < 0 || (size_t)pid >= numels.size()) throw std::invalid_argument("plan_buckets: bad parameter index");
-  for (long e : esz)
-    if (e <= 0) throw std::invalid_argument("plan_buckets: bad element size");
-  std::vector<PlannedBucket> out;
-  size_t split = order.size();
-  if (last_cap > 0 && order.size() > 1) {
-    long acc = 0;
-    while (split > 0) {
-      const long pid = order[split - 1];
-      const long sz = numels[pid] * esz[pid];
-      if (split < order.size() && acc + sz > last_cap) break;
-      acc += sz;
-      --split;
-    }
-    if (split == 0) split = order.size();       // everything fits the tail: plan normally
-  }
-  plan_range(numels, esz, dkeys, order, 0, split, cap, first_cap, align, out);
-  const long inf = 1L << 62;
-  plan_range(numels, esz, dkeys, order, split, order.size(), inf, inf, align, out);
-  std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> res;
-  res.reserve(out.size());
-  for (auto& b : out) res.emplace_back(b.dtype_key, std::move(b.pids), std::move(b.offsets), b.total);
-  return res;
-}
 
 }  // namespace
 
 void bind_comm(py::module_& m) {
-  m.def("plan_buckets", &plan_buckets, py::arg("numels"), py::arg("elem_sizes"), py::arg("dtype_keys"),
+  m.def("plan_buckets", &dpa::comm::plan_buckets, py::arg("numels"), py::arg("elem_sizes"), py::arg("dtype_keys"),
         py::arg("order"), py::arg("cap_bytes"), py::arg("first_cap_bytes"), py::arg("align_bytes") = 256,
         py::arg("last_cap_bytes") = 0);
+  m.attr("WATCHDOG_EXIT_CODE") = (int)dpa::comm::kWatchdogExitCode;
   m.def("rccl_version", &Communicator::version);
   m.def("rccl_unique_id", &Communicator::unique_id);
   py::class_<Communicator, std::shared_ptr<Communicator>>(m, "Communicator")
@@ -404,6 +327,8 @@ void bind_comm(py::module_& m) {
            py::arg("device"))
       .def("all_reduce", &Communicator::all_reduce, py::arg("ptr"), py::arg("count"), py::arg("dtype"),
            py::arg("average") = false, py::arg("stream") = 0)
+      .def("all_reduce_max", &Communicator::all_reduce_max, py::arg("ptr"), py::arg("count"), py::arg("dtype"),
+           py::arg("stream") = 0)
       .def("broadcast", &Communicator::broadcast, py::arg("ptr"), py::arg("nbytes"), py::arg("root") = 0,
            py::arg("stream") = 0)
       .def("all_gather", &Communicator::all_gather, py::arg("send"), py::arg("recv"), py::arg("count"),
@@ -411,20 +336,38 @@ void bind_comm(py::module_& m) {
       .def("comm_waits_for", &Communicator::comm_waits_for)
       .def("wait_comm", &Communicator::wait_comm)
       .def("synchronize", &Communicator::synchronize)
-      .def("abort", &Communicator::abort)
+      .def("abort", &Communicator::abort, py::call_guard<py::gil_scoped_release>())
       .def("async_error", &Communicator::async_error)
+      .def_property_readonly("aborted", &Communicator::aborted)
       .def_property_readonly("rank", &Communicator::rank)
       .def_property_readonly("world_size", &Communicator::world)
       .def_property_readonly("stream", &Communicator::stream_handle);
-  py::class_<BucketReducer>(m, "BucketReducer")
-      .def(py::init<std::shared_ptr<Communicator>, std::vector<uintptr_t>, std::vector<size_t>, std::vector<int>,
-                    std::vector<int>>(),
-           py::arg("comm"), py::arg("bucket_ptrs"), py::arg("bucket_counts"), py::arg("bucket_dtypes"),
-           py::arg("param_bucket"))
-      .def("prepare", &BucketReducer::prepare)
-      .def("mark_ready", &BucketReducer::mark_ready)
-      .def("flush", &BucketReducer::flush)
-      .def("finalize", &BucketReducer::finalize)
-      .def_property_readonly("num_buckets", &BucketReducer::num_buckets)
-      .def_property_readonly("launched", &BucketReducer::launched);
+  py::class_<ReduceBackend, std::shared_ptr<ReduceBackend>>(m, "ReduceBackend");
+  py::class_<RcclBackend, ReduceBackend, std::shared_ptr<RcclBackend>>(m, "RcclBackend")
+      .def(py::init<std::shared_ptr<Communicator>>(), py::arg("comm"));
+  py::class_<HostBackend, ReduceBackend, std::shared_ptr<HostBackend>>(m, "HostBackend")
+      .def(py::init([](const std::string& host, int port, int rank, int world, double timeout_s,
+                       const std::string& tag) {
+             py::gil_scoped_release nogil;
+             return std::make_shared<HostBackend>(host, port, rank, world, timeout_s, tag);
+           }),
+           py::arg("host"), py::arg("port"), py::arg("rank"), py::arg("world_size"), py::arg("timeout_s") = 300.0,
+           py::arg("tag") = "0")
+      .def_property_readonly("collectives", &HostBackend::collectives);
+  py::class_<PyReducer>(m, "BucketReducer")
+      .def(py::init<std::shared_ptr<ReduceBackend>, std::vector<uintptr_t>, std::vector<size_t>, std::vector<int>,
+                    std::vector<int>, size_t, double, bool, double>(),
+           py::arg("backend"), py::arg("bucket_ptrs"), py::arg("bucket_counts"), py::arg("bucket_dtypes"),
+           py::arg("param_bucket"), py::arg("chunk_bytes") = (size_t)128 << 20, py::arg("timeout_s") = 0.0,
+           py::arg("exit_on_timeout") = true, py::arg("grace_s") = 10.0)
+      .def("prepare", &PyReducer::prepare)
+      .def("mark_ready", &PyReducer::mark_ready)
+      .def("flush", &PyReducer::flush)
+      .def("finalize", &PyReducer::finalize)
+      .def("observed_order", &PyReducer::observed_order)
+      .def_property_readonly("num_buckets", &PyReducer::num_buckets)
+      .def_property_readonly("launched", &PyReducer::launched)
+      .def_property_readonly("collectives", &PyReducer::collectives)
+      .def_property_readonly("failed", &PyReducer::failed)
+      .def_property_readonly("failure", &PyReducer::failure);
 }

@@ -71,6 +71,11 @@ __global__ __launch_bounds__(kThreads) void oneshot_allreduce_kernel(float* __re
   }
   __syncthreads();
   if (timed_out) {
+    // The sum never happened.  Poison the output so that whatever consumes it next (the loss, the scaler's finite
+    // check, a checkpointed running statistic) shows it, and raise the host-visible status word: the host checks
+    // it at every later all_reduce(), optimizer step, barrier and checkpoint (NativeComm.check_health).  This
+    // object must not be used again -- the ranks' sequence numbers no longer agree.
+    for (int i = tid; i < n; i += kThreads) data[i] = __uint_as_float(0x7fc00000u);
     if (tid == 0) __hip_atomic_store(status, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }

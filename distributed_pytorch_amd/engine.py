@@ -107,6 +107,9 @@ def main_worker(local_rank: int, ngpus_per_node: int, args) -> None:
         device = torch.device("cpu")
         if script == "nd":
             print("using CPU, this will be slow")
+    if getattr(args, "distributed", False) or "LOCAL_WORLD_SIZE" in os.environ:
+        # CPUs next to this rank's GPU (its NUMA node), for ranks of our launcher and of torchrun alike
+        launch.set_affinity_from_env(use_gpu=use_gpu)
     if args.profile:
         profiling.enable(True)
 
@@ -325,6 +328,9 @@ class _Run:
         end = time.time()
         win_start, win_iters, lr = end, 0, self.optimizer.param_groups[0]["lr"]
         thr_avg = AverageMeter("Throughput", ":.1f")
+        # the iteration this epoch really ends at: --steps may cut a real dataset short, and the meters must be
+        # flushed there (by every rank together: the flush is a collective under the AMP script)
+        n_stop = min(n_iter, args.steps) if args.steps else n_iter
         i = 0
         while True:
             with profiling.range_("data"):
@@ -352,7 +358,7 @@ class _Run:
             dm.update(rec)
             self.global_step += 1
             win_iters += 1
-            if i % args.print_freq == 0 or i == n_iter:
+            if i % args.print_freq == 0 or i == n_stop:
                 (l_loss, l_a1, l_a5, l_n), (r_loss, r_a1, r_a5, r_n) = DeviceMeter.unpack(
                     self._reduced(dm.packed()).cpu())          # the ONE host sync of the window
                 now = time.time()
@@ -375,7 +381,7 @@ class _Run:
                            "top5": l_a5, "time": per_iter, "throughput": thr, "lr": lr})
                 win_start, win_iters = time.time(), 0
             end = time.time()
-            if args.steps and i >= args.steps:
+            if i >= n_stop:
                 break
         return {"throughput": thr_avg.avg, "batch_time": batch_time.avg, "loss": losses.avg,
                 "top1": top1.avg, "top5": top5.avg, "lr": lr}
@@ -393,6 +399,7 @@ class _Run:
         self.model.eval()
         pre = self._prefetcher(loader)
         start = win_start = time.time()
+        n_stop = min(n_iter, max(1, args.steps // 4)) if args.steps else n_iter
         i = win_iters = 0
         with torch.no_grad():
             while True:
@@ -404,7 +411,7 @@ class _Run:
                 _, rec = F.loss_and_metrics(output, target)
                 dm.update(rec)
                 win_iters += 1
-                if i % args.print_freq == 0 or i == n_iter:
+                if i % args.print_freq == 0 or i == n_stop:
                     (l_loss, l_a1, l_a5, _), (r_loss, r_a1, r_a5, r_n) = DeviceMeter.unpack(
                         self._reduced(dm.packed()).cpu())
                     per_iter = (time.time() - win_start) / max(win_iters, 1)
@@ -421,7 +428,7 @@ class _Run:
                     else:
                         progress.display(i)
                     win_start, win_iters = time.time(), 0
-                if args.steps and i >= max(1, args.steps // 4):
+                if i >= n_stop:
                     break
         if script == "nd":
             progress.display_summary()

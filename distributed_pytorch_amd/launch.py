@@ -20,7 +20,7 @@ import signal
 import sys
 import time
 import traceback
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 
@@ -55,20 +55,88 @@ def parse_dist_url(url: str) -> Tuple[str, Optional[str], Optional[int]]:
     raise ValueError("unsupported --dist-url %r" % url)
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def global_rank(node_rank: int, ngpus_per_node: int, local_rank: int) -> int:
     return node_rank * ngpus_per_node + local_rank
 
 
-def set_affinity(local_rank: int, nprocs: int) -> None:
-    """Give each rank a contiguous slice of the CPUs this process may use."""
+def _cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_node(device_index: int) -> Optional[int]:
+    """NUMA node that owns GPU ``device_index`` (``/sys/bus/pci/devices/<bdf>/numa_node``), None when unknown."""
     try:
-        cpus = sorted(os.sched_getaffinity(0))
-        share = max(1, len(cpus) // max(1, nprocs))
-        mine = cpus[local_rank * share:(local_rank + 1) * share] or cpus
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except Exception:  # noqa: BLE001  (no GPU, no sysfs, old torch)
+        return None
+
+
+def numa_cpus(node: int) -> List[int]:
+    try:
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            return _cpulist(f.read())
+    except OSError:
+        return []
+
+
+def plan_affinity(local_rank: int, nprocs: int, allowed: List[int], nodes: List[Optional[int]],
+                  node_cpus) -> List[int]:
+    """CPUs for ``local_rank``: the allowed CPUs of the NUMA node its GPU hangs off, divided among the local ranks
+    whose GPUs share that node (pinned input buffers and the H2D copies then stay node-local); an even slice of
+    the allowed CPUs when the topology is unknown.  Pure function of its inputs (tested on fake topologies)."""
+    allowed = sorted(allowed)
+    node = nodes[local_rank] if local_rank < len(nodes) else None
+    if node is not None:
+        local = [c for c in node_cpus(node) if c in set(allowed)]
+        peers = [r for r in range(min(nprocs, len(nodes))) if nodes[r] == node]
+        if local and local_rank in peers:
+            share = max(1, len(local) // len(peers))
+            k = peers.index(local_rank)
+            mine = local[k * share:(k + 1) * share]
+            if mine:
+                return mine
+    share = max(1, len(allowed) // max(1, nprocs))
+    return allowed[local_rank * share:(local_rank + 1) * share] or allowed
+
+
+def set_affinity(local_rank: int, nprocs: int, use_gpu: bool = False) -> List[int]:
+    """Pin this rank to the CPUs next to its GPU (see ``plan_affinity``).  Call after ``set_device``."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        nodes = [gpu_numa_node(i) for i in range(nprocs)] if use_gpu else [None] * nprocs
+        mine = plan_affinity(local_rank, nprocs, allowed, nodes, numa_cpus)
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(len(mine), 16)))
+        return mine
     except (AttributeError, OSError):
-        pass
+        return []
+
+
+def set_affinity_from_env(use_gpu: bool = True) -> List[int]:
+    """Ranks started by an external launcher (torchrun) get the same placement as ``spawn``'s children."""
+    if os.environ.get("DPA_AFFINITY", "1") == "0":
+        return []
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    n = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return set_affinity(lr, max(n, lr + 1), use_gpu=use_gpu)
 
 
 def init_process_group(backend: str, init_method: str, world_size: int, rank: int,
@@ -102,8 +170,8 @@ def _register(pid: int) -> str:
 
 def _child(fn: Callable, local_rank: int, nprocs: int, args: tuple, err_q) -> None:
     os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ["LOCAL_WORLD_SIZE"] = str(nprocs)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    set_affinity(local_rank, nprocs)
     try:
         fn(local_rank, *args)
     except KeyboardInterrupt:

@@ -16,16 +16,10 @@ import torch
 import torch.nn.functional as TF
 
 
-import os as _os
-
-# DPA_TORCH_BASELINE=1 routes GPU tensors through the stock PyTorch ops below (MIOpen / rocBLAS /
-# ATen).  It exists ONLY to measure the "stock PyTorch-ROCm" baseline of BASELINE.md on the same
-# model definition; the framework never takes this path by itself.
-_TORCH_BASELINE = _os.environ.get("DPA_TORCH_BASELINE", "0") == "1"
-
-
 def _on_gpu(t: torch.Tensor) -> bool:
-    return t.is_cuda and not _TORCH_BASELINE
+    """GPU tensors ALWAYS run the HIP kernels; the PyTorch ops below are the CPU reference backend.  (The stock
+    PyTorch-ROCm comparison point lives outside the framework: ``bench/torch_baseline.py``.)"""
+    return t.is_cuda
 
 
 def _hip():

@@ -23,6 +23,7 @@ import torch
 from torch.optim import Optimizer
 
 from . import amp as _amp
+from .parallel import process_group as _pg
 
 
 class FusedSGD(Optimizer):
@@ -66,13 +67,11 @@ class FusedSGD(Optimizer):
         """Gradient arenas behind this optimizer's parameters.  On the GPU every fp32 parameter
         gets one (DDP's buckets, or a private flat arena on a single GPU) so backward kernels write
         gradients in place and the device tensor table never changes."""
-        from .ops import functional as _F
-
         params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
         if not params:
             return []
         missing = [p for p in params if getattr(p, "_dpa_sink", None) is None]
-        if missing and not _F._TORCH_BASELINE and all(p.is_cuda and p.dtype == torch.float32 for p in missing):
+        if missing and all(p.is_cuda and p.dtype == torch.float32 for p in missing):
             from .parallel.distributed import GradArena
 
             self._own_arena = GradArena(missing)
@@ -113,11 +112,11 @@ class FusedSGD(Optimizer):
         from .ops import hip_ops as _hip_ops
 
         _hip_ops.join_side_stream()
+        if _pg.is_initialized():
+            _pg.check_health()          # a timed-out SyncBN / metric all-reduce must not reach the weights
         for arena in self._arenas():
             arena.finish_step()
-        from .ops import functional as _F
-
-        any_cuda = not _F._TORCH_BASELINE and any(p.is_cuda for g in self.param_groups for p in g["params"])
+        any_cuda = any(p.is_cuda for g in self.param_groups for p in g["params"])
         if any_cuda:
             self._step_hip(scaler)
         else:

@@ -19,6 +19,14 @@ Capability parity with what the reference gets from
   stream back -- no host synchronisation.  On the GPU this state machine is the C++
   ``BucketReducer`` calling RCCL directly (``csrc/comm/comm.cpp``); with the ``gloo`` backend
   (CPU plumbing configuration) the same logic runs in Python over ``torch.distributed``.
+* **Chunking**: a bucket larger than ``chunk_mb`` (VGG-16 ``fc6.weight`` alone is 392 MiB) travels as
+  back-to-back slices (``reducer_core.cpp``).
+* **Re-planning**: buckets are first planned in reverse registration order; the order in which gradients
+  REALLY became ready is recorded during the first synchronised backward, rank 0's is broadcast, and
+  the arena is rebuilt from it once (what c10d's Reducer does behind ``imagenet_ddp.py:127``) -- it matters
+  for Inception / GoogLeNet / DenseNet, whose registration order is not their backward order.
+* **Watchdog**: a bucket whose all-reduce does not complete within ``collective_timeout_s`` aborts the
+  communicator (``ncclCommAbort``) and fails the rank, so the launcher tears the job down.
 * ``delay_allreduce=True``: one flat bucket per dtype, reduced after backward (Apex mode).
 * Init: parameter-shape verification across ranks, then rank-0 broadcast of the flat parameter
   and buffer arenas (C-c); optional per-forward buffer broadcast (C-d, ``broadcast_buffers``).
@@ -152,13 +160,27 @@ class _PyReducer:
     def __init__(self, ddp, arena: GradArena):
         self.ddp, self.arena = ddp, arena
         self.next = 0
+        self._order: List[int] = []
+        self._observed: List[int] = []
+        self._seen = set()
+        self.collectives = 0
 
     def prepare(self):
         for b in self.arena.buckets:
             b.pending, b.launched, b.work = len(b.params), False, []
         self.next = 0
+        if self._order:
+            self._observed, self._order = self._order, []
+        self._seen = set()
+
+    def observed_order(self) -> List[int]:
+        return list(self._observed)
 
     def mark_ready(self, pid: int):
+        if pid in self._seen:
+            return
+        self._seen.add(pid)
+        self._order.append(pid)
         b = self.arena.buckets[self.arena.bucket_of[pid]]
         if b.pending <= 0:
             return
@@ -185,6 +207,7 @@ class _PyReducer:
         pieces = [b.flat]
         if nbytes > ddp.chunk_bytes:
             pieces = [b.flat[s:e] for s, e in chunk_ranges(b.flat.numel(), b.flat.element_size(), ddp.chunk_bytes)]
+        self.collectives += len(pieces)
         if ddp.on_gpu and ddp.comm_stream is not None:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(ddp.device))
@@ -208,12 +231,18 @@ class _PyReducer:
 
 
 class _NativeReducer:
-    """C++ BucketReducer: RCCL all-reduce per bucket on the communicator's stream."""
+    """C++ BucketReducer (``csrc/comm/reducer_core.cpp``): RCCL all-reduce per bucket slice on the communicator's
+    stream on a GPU, the TcpStore-backed host backend with a worker thread on the CPU -- one state machine."""
 
     def __init__(self, ddp, arena: GradArena):
         self.ddp, self.arena = ddp, arena
         pb = [arena.bucket_of[i] for i in range(len(arena.params))]
-        self.raw = ddp.comm.make_reducer(arena.flat_buffers(), pb)
+        self.raw = ddp.comm.make_reducer(arena.flat_buffers(), pb, chunk_bytes=ddp.chunk_bytes,
+                                         timeout_s=ddp.collective_timeout_s,
+                                         exit_on_timeout=ddp.exit_on_timeout)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream().cuda_stream if self.ddp.on_gpu else 0
 
     def prepare(self):
         self.raw.prepare()
@@ -221,24 +250,44 @@ class _NativeReducer:
     def mark_ready(self, pid: int):
         if self.ddp.delay_allreduce:
             return
-        self.raw.mark_ready(pid, torch.cuda.current_stream().cuda_stream)
+        self.raw.mark_ready(pid, self._stream())
 
     def finalize(self):
-        self.raw.finalize(torch.cuda.current_stream().cuda_stream)
+        self.raw.finalize(self._stream())
+
+    def observed_order(self) -> List[int]:
+        return list(self.raw.observed_order())
+
+    @property
+    def collectives(self) -> int:
+        return self.raw.collectives
 
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
                  bucket_cap_mb: float = 64.0, first_bucket_mb: float = 4.0, last_bucket_mb: float = 2.0,
                  delay_allreduce: bool = False, broadcast_buffers: bool = True,
-                 comm: str = "auto", chunk_mb: float = 128.0, verify_shapes: bool = True):
+                 comm: str = "auto", chunk_mb: float = 128.0, verify_shapes: bool = True,
+                 collective_timeout_s: Optional[float] = None, replan: bool = True,
+                 exit_on_timeout: bool = True):
         super().__init__()
+        import os as _os
+
         self.module = module
         self.delay_allreduce = delay_allreduce
         self.broadcast_buffers = broadcast_buffers
         self.cap_bytes = int(bucket_cap_mb * MiB)
         self.first_cap_bytes = int(first_bucket_mb * MiB)
-        self.chunk_bytes = int(chunk_mb * MiB)
+        self.last_cap_bytes = int(last_bucket_mb * MiB)
+        self.chunk_bytes = int(float(_os.environ.get("DPA_CHUNK_MB", chunk_mb)) * MiB)
+        if collective_timeout_s is None:
+            collective_timeout_s = float(_os.environ.get("DPA_COLLECTIVE_TIMEOUT_S", "600"))
+        self.collective_timeout_s = float(collective_timeout_s)
+        self.exit_on_timeout = exit_on_timeout
+        self._replan_state = "observe" if (replan and not delay_allreduce
+                                           and _os.environ.get("DPA_REPLAN", "1") == "1") else "off"
+        self._new_order: Optional[List[int]] = None
+        self.replans = 0
         self.require_backward_grad_sync = True
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -259,18 +308,53 @@ class DistributedDataParallel(nn.Module):
         self._buffer_arena()
         self._callback_queued = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes,
-                               single_bucket=delay_allreduce, on_ready=self._on_sink_ready,
-                               last_cap_bytes=int(last_bucket_mb * MiB))
+        self._order = list(range(len(self.params) - 1, -1, -1))     # reverse registration order until observed
+        self._build_arena(self._order)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._autograd_hook)
+
+    def _build_arena(self, order: List[int]) -> None:
         import os as _os
 
+        self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes, order=order,
+                               single_bucket=self.delay_allreduce, on_ready=self._on_sink_ready,
+                               last_cap_bytes=self.last_cap_bytes)
         force = _os.environ.get("DPA_FORCE_NATIVE_REDUCER", "0") == "1"     # world_size 1 test hook
         self.reducer = _NativeReducer(self, self.arena) if (self.native and (self.world_size > 1 or force)) \
             else _PyReducer(self, self.arena)
         self.reducer.prepare()
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._autograd_hook)
         self.comm_bytes_per_step = sum(b.flat.numel() * b.flat.element_size() for b in self.arena.buckets)
+
+    # ------------------------------------------------------------------ bucket re-planning
+    def _observe_order(self) -> None:
+        """After the first synchronised backward: adopt rank 0's observed gradient-ready order if it packs the
+        parameters into different buckets than the registration-order guess did."""
+        self._replan_state = "done"
+        seen = self.reducer.observed_order()
+        if not seen:
+            return
+        have = set(seen)
+        order = list(seen) + [i for i in self._order if i not in have]      # unused parameters keep their place
+        t = torch.tensor(order, dtype=torch.int64, device=self.device)
+        if self.world_size > 1:
+            self.comm.broadcast(t, 0)
+        order = [int(v) for v in t.cpu().tolist()]
+        if sorted(order) != list(range(len(self.params))):
+            return
+        if order != self._order:
+            self._new_order = order
+
+    def _maybe_rebuild(self) -> None:
+        """Start of a forward pass: swap in the arena planned from the observed order.  Waits for a moment when
+        no gradient of the current iteration lives in the old arena (gradient accumulation in flight)."""
+        if self._new_order is None or any(s.written for s in self.arena.sinks):
+            return
+        order, self._new_order = self._new_order, None
+        for p in self.params:
+            p.grad = None                   # stale values of the previous step, consumed by the optimizer
+        self._order = order
+        self._build_arena(order)
+        self.replans += 1
 
     # ------------------------------------------------------------------ init-time sync
     def _verify_shapes(self) -> None:
@@ -333,6 +417,8 @@ class DistributedDataParallel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, *inputs, **kwargs):
+        if self._new_order is not None and self.module.training and torch.is_grad_enabled():
+            self._maybe_rebuild()
         if self.world_size > 1 and self.broadcast_buffers and self.module.training \
                 and self.require_backward_grad_sync:
             for flat in self._buf_flat:
@@ -384,6 +470,8 @@ class DistributedDataParallel(nn.Module):
         self.arena.finish_step()
         self.reducer.finalize()
         self.reducer.prepare()
+        if self._replan_state == "observe" and self.require_backward_grad_sync:
+            self._observe_order()
 
     # ------------------------------------------------------------------ conveniences
     def zero_grad(self, set_to_none: bool = False) -> None:
@@ -398,3 +486,12 @@ class DistributedDataParallel(nn.Module):
     def bucket_summary(self) -> List[dict]:
         return [{"bucket": i, "params": len(b.params), "mbytes": b.flat.numel() * b.flat.element_size() / MiB}
                 for i, b in enumerate(self.arena.buckets)]
+
+    def comm_summary(self) -> dict:
+        """What the benchmark prints: how the gradients travel."""
+        sizes = [b.flat.numel() * b.flat.element_size() for b in self.arena.buckets]
+        return {"backend": getattr(self.comm, "backend", "none") if self.comm is not None else "none",
+                "reducer": "c++" if isinstance(self.reducer, _NativeReducer) else "python",
+                "ranks": self.world_size, "buckets": len(sizes), "bucket_mbytes": [round(s / MiB, 1) for s in sizes],
+                "bytes_per_step": int(sum(sizes)), "chunk_mbytes": self.chunk_bytes / MiB,
+                "replanned": self.replans, "collectives": int(self.reducer.collectives)}

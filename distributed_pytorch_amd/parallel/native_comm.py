@@ -1,11 +1,13 @@
 """NativeComm — the C++ RCCL communicator (``csrc/comm/comm.cpp``) behind the ``TorchComm`` interface.
 
 The RCCL unique id is created by rank 0 in C++ (``ncclGetUniqueId``) and published through the
-rendezvous store of the already-initialised ``torch.distributed`` process group (TCPStore for
+rendezvous STORE of the already-initialised ``torch.distributed`` process group (TCPStore for
 ``tcp://``, the env store for ``env://`` -- same rendezvous flags as the reference,
-``nd_imagenet.py:130-131``); every rank then calls ``ncclCommInitRank`` itself.  Collectives run on
-the communicator's own high-priority HIP stream; ``wait()`` handles order the *current* stream
-after them with an event -- no host synchronisation.
+``nd_imagenet.py:130-131``); every rank then calls ``ncclCommInitRank`` itself.  Only the store is
+used, never a torch collective, so torch's own (lazily created) RCCL communicator is not built and the
+process holds ONE communicator.  Collectives run on the communicator's own HIP stream (normal priority,
+see ``csrc/comm/comm.cpp``); ``wait()`` handles order the *current* stream after them with an event --
+no host synchronisation.
 """
 from __future__ import annotations
 
@@ -70,19 +72,41 @@ class NativeComm:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         device = torch.cuda.current_device()
         _COUNTER[0] += 1
-        # exchange the unique id through the process group itself (works for every rendezvous kind)
-        holder = [ext.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(holder, src=dist.get_global_rank(group, 0) if group is not None else 0,
-                                   group=group)
-        raw = ext.Communicator(holder[0], rank, world, device)
+        gen = _COUNTER[0]
+        store = dist.distributed_c10d._get_default_store()
+        if group is not None:
+            store = dist.PrefixStore("dpa_group_%d" % hash(tuple(dist.get_process_group_ranks(group))), store)
+        seq = [0]
 
         def exchange(payload: bytes):
-            out = [None] * world
-            dist.all_gather_object(out, payload, group=group)
-            return out
+            """Collective over the store: bytes of this rank -> list of every rank's bytes."""
+            seq[0] += 1
+            base = "dpa/native/%d/x%d" % (gen, seq[0])
+            store.set("%s/%d" % (base, rank), payload)
+            return [payload if r == rank else bytes(store.get("%s/%d" % (base, r))) for r in range(world)]
 
-        comm = cls(raw, group, exchange)
-        comm._self_test()
+        # exchange the unique id through the process group's store (works for every rendezvous kind)
+        uid_key = "dpa/native/%d/uid" % gen
+        if rank == 0:
+            store.set(uid_key, bytes(ext.rccl_unique_id()))
+        uid = bytes(store.get(uid_key))
+        # build + verify, then agree: either every rank uses the native communicator or none does (a rank that
+        # failed alone would leave the others waiting inside their first collective)
+        comm, err = None, ""
+        try:
+            comm = cls(ext.Communicator(uid, rank, world, device), group, exchange)
+            comm._self_test()
+        except Exception as exc:  # noqa: BLE001
+            err = "rank %d: %r" % (rank, exc)
+        errs = [e.decode() for e in exchange(err.encode()) if e]
+        if errs:
+            if comm is not None:
+                _shared[0] = None
+                try:
+                    comm.raw.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+            raise RuntimeError("native RCCL communicator unavailable on at least one rank: " + "; ".join(errs))
         return comm
 
     # ------------------------------------------------------------------ small-message peer path
@@ -133,6 +157,15 @@ class NativeComm:
             self._p2p = self._setup_p2p()
         return self._p2p or None
 
+    def check_health(self) -> None:
+        """Raises when an earlier one-shot peer all-reduce timed out (its output was filled with NaN on the device
+        and the ranks' slot protocol is out of step: the job has to stop).  Cheap -- one read of a host-mapped
+        word -- and called at every optimizer step, barrier and checkpoint."""
+        peer = self._p2p
+        if peer and peer.status() != 0:
+            raise RuntimeError("one-shot peer all-reduce %d timed out: a peer rank did not arrive (dead or hung); "
+                               "its result was poisoned with NaN -- aborting this rank" % peer.status())
+
     def _small(self, t: torch.Tensor) -> bool:
         if t.dtype != torch.float32 or not t.is_cuda or t.numel() > P2P_CAPACITY_FLOATS or not t.is_contiguous() \
                 or self._p2p is False:
@@ -140,6 +173,7 @@ class NativeComm:
         peer = self.peer_path()
         if peer is None:
             return False
+        self.check_health()
         peer.all_reduce(t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
         self.p2p_calls += 1
         return True
@@ -193,12 +227,22 @@ class NativeComm:
         self.raw.all_gather(t.data_ptr(), out.data_ptr(), t.numel(), _DT[t.dtype], 0)
         _StreamWait(self.raw).wait()
 
+    def all_reduce_max(self, t: torch.Tensor):
+        self._order_after_current()
+        self.raw.all_reduce_max(t.data_ptr(), t.numel(), _DT[t.dtype], 0)
+        h = _StreamWait(self.raw)
+        h.wait()
+        return h
+
     def barrier(self):
         t = torch.zeros(1, dtype=torch.float32, device="cuda")
         self._rccl_sum(t).wait()
         torch.cuda.current_stream().synchronize()
 
-    def make_reducer(self, flats, param_bucket):
+    def make_reducer(self, flats, param_bucket, chunk_bytes: int = 128 << 20, timeout_s: float = 0.0,
+                     exit_on_timeout: bool = True, grace_s: float = 10.0):
+        """The C++ BucketReducer on this communicator's stream (``csrc/comm/reducer_core.cpp`` + RcclBackend)."""
         ext = backend.require()
-        return ext.BucketReducer(self.raw, [f.data_ptr() for f in flats], [f.numel() for f in flats],
-                                 [_DT[f.dtype] for f in flats], list(param_bucket))
+        return ext.BucketReducer(ext.RcclBackend(self.raw), [f.data_ptr() for f in flats],
+                                 [f.numel() for f in flats], [_DT[f.dtype] for f in flats], list(param_bucket),
+                                 int(chunk_bytes), float(timeout_s or 0.0), bool(exit_on_timeout), float(grace_s))

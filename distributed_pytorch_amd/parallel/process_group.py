@@ -17,8 +17,8 @@ job to the native runtime.
 from __future__ import annotations
 
 import datetime
+import json
 import os
-import pickle
 from typing import Optional
 
 import torch
@@ -100,8 +100,49 @@ class StoreComm:
         for r, p in enumerate(parts):
             out[r].copy_(torch.frombuffer(bytearray(p), dtype=torch.uint8).view(t.dtype).view_as(t))
 
+    def all_reduce_max(self, t: torch.Tensor):
+        if self.world_size > 1:
+            flat = t.detach().contiguous().view(-1)
+            parts = self._exchange(flat.to(torch.float64).numpy().tobytes())
+            acc = torch.frombuffer(bytearray(parts[0]), dtype=torch.float64).clone()
+            for p in parts[1:]:
+                acc = torch.maximum(acc, torch.frombuffer(bytearray(p), dtype=torch.float64))
+            t.copy_(acc.to(t.dtype).view_as(t))
+        return _Done()
+
     def barrier(self):
         self.store.barrier("pg", self.world_size)
+
+    def make_reducer(self, flats, param_bucket, chunk_bytes: int = 128 << 20, timeout_s: float = 0.0,
+                     exit_on_timeout: bool = True, grace_s: float = 10.0):
+        """The C++ BucketReducer over host memory: the same state machine that drives RCCL on a GPU, with a
+        worker thread + the TcpStore as its communication queue (``csrc/comm/host_backend.cpp``)."""
+        from .. import backend as _backend
+
+        ext = _backend.require()
+        _REDUCER_GEN[0] += 1
+        # the worker's own store timeout sits well behind the watchdog's: a silent peer is the watchdog's case
+        be = ext.HostBackend(self.store.host, self.store.port, self.rank, self.world_size,
+                             3.0 * float(timeout_s) + 30.0 if timeout_s and timeout_s > 0 else 300.0,
+                             "g%d" % _REDUCER_GEN[0])
+        return ext.BucketReducer(be, [f.data_ptr() for f in flats], [f.numel() for f in flats],
+                                 [_HOST_DT[f.dtype] for f in flats], list(param_bucket), int(chunk_bytes),
+                                 float(timeout_s or 0.0), bool(exit_on_timeout), float(grace_s))
+
+
+_REDUCER_GEN = [0]      # reducers are built in the same order on every rank: the count names their store keys
+_HOST_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _agent_store():
+    """torchrun's rendezvous store (it owns MASTER_PORT while the job runs), used for ONE key: the port of our
+    own TcpStore.  None when the job was not started by torchrun."""
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() != "true":
+        return None
+    import torch.distributed as dist
+
+    return dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), None, False,
+                         datetime.timedelta(seconds=120))
 
 
 class NativeProcessGroup:
@@ -120,7 +161,18 @@ class NativeProcessGroup:
         if scheme == "file" or host is None or port is None:
             raise ValueError("the native process group needs tcp://host:port or env:// with MASTER_ADDR/MASTER_PORT")
         self.rank, self.world_size = int(rank), int(world_size)
-        self.store = ext.TcpStore(host, int(port), self.rank == 0, float(timeout_s))
+        agent = _agent_store() if scheme == "env" else None
+        if agent is not None:
+            # under torchrun MASTER_PORT belongs to the agent's store: ours takes an ephemeral port that rank 0
+            # publishes through it
+            key = "dpa/native_store_port/%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+            if self.rank == 0:
+                self.store = ext.TcpStore(host, 0, True, float(timeout_s))
+                agent.set(key, str(self.store.port))
+            else:
+                self.store = ext.TcpStore(host, int(agent.get(key).decode()), False, float(timeout_s))
+        else:
+            self.store = ext.TcpStore(host, int(port), self.rank == 0, float(timeout_s))
         self.host_comm = StoreComm(self.store, self.rank, self.world_size)
         self.gpu_comm = None
         use_gpu = torch.cuda.is_available() if use_gpu is None else use_gpu
@@ -133,9 +185,19 @@ class NativeProcessGroup:
             if self.rank == 0:
                 self.store.set("rccl_unique_id", bytes(ext.rccl_unique_id()))
             uid = self.store.get("rccl_unique_id")
-            raw = ext.Communicator(uid, self.rank, self.world_size, torch.cuda.current_device())
-            self.gpu_comm = NativeComm(raw, None, self.host_comm._exchange)
-            self.gpu_comm._self_test()
+            # every rank learns whether EVERY rank built and verified its communicator: a rank that failed alone
+            # would otherwise leave the others waiting inside their first collective
+            err = ""
+            try:
+                raw = ext.Communicator(uid, self.rank, self.world_size, torch.cuda.current_device())
+                self.gpu_comm = NativeComm(raw, None, self.host_comm._exchange)
+                self.gpu_comm._self_test()
+            except Exception as exc:  # noqa: BLE001
+                err = "rank %d: %r" % (self.rank, exc)
+            errs = [e.decode() for e in self.host_comm._exchange(err.encode()) if e]
+            if errs:
+                self.gpu_comm = None
+                raise RuntimeError("native RCCL communicator could not be built: " + "; ".join(errs))
 
     def comm_for(self, t: Optional[torch.Tensor] = None):
         if t is not None and t.is_cuda:
@@ -145,11 +207,12 @@ class NativeProcessGroup:
         return self.host_comm
 
     def broadcast_object(self, obj, src: int = 0):
+        """JSON only: store contents are bytes from the network and are never unpickled."""
         key = "obj/%d" % self.store.add("obj_seq/%d" % self.rank, 1)
         if self.rank == src:
-            self.store.set(key, pickle.dumps(obj))
+            self.store.set(key, json.dumps(obj).encode())
             return obj
-        return pickle.loads(self.store.get(key))       # our own bytes, written by rank `src` of this job
+        return json.loads(self.store.get(key).decode())
 
     def barrier(self):
         self.store.barrier("pg", self.world_size)
@@ -159,7 +222,9 @@ class NativeProcessGroup:
     def destroy(self):
         self.gpu_comm = None
         self.host_comm = None
-        self.store = None
+        store, self.store = self.store, None
+        if store is not None:
+            store.close()       # rank 0 keeps serving until the other ranks have hung up (store_core.h)
 
 
 # ------------------------------------------------------------------------------- module-level API
@@ -212,11 +277,43 @@ def get_backend() -> str:
     return _tdist().get_backend() if is_initialized() else "none"
 
 
+def check_health() -> None:
+    """Surface asynchronous communication failures (a timed-out peer all-reduce) on the host."""
+    from .native_comm import shared
+
+    nc = shared()
+    if nc is not None:
+        nc.check_health()
+
+
 def barrier() -> None:
+    check_health()
     if _NATIVE is not None:
         _NATIVE.barrier()
     elif is_initialized():
-        _tdist().barrier()
+        d = _tdist()
+        if d.get_backend() == "nccl":
+            # host-side barrier through the rendezvous store: no collective, hence no second RCCL communicator
+            from .native_comm import shared
+
+            if shared() is not None:
+                torch.cuda.current_stream().synchronize()
+                _store_barrier(d)
+                return
+        d.barrier()
+
+
+_BARRIER_SEQ = [0]
+
+
+def _store_barrier(d) -> None:
+    store = d.distributed_c10d._get_default_store()
+    world = d.get_world_size()
+    _BARRIER_SEQ[0] += 1
+    key = "dpa/barrier/%d" % _BARRIER_SEQ[0]
+    if store.add(key, 1) == world:
+        store.set(key + "/go", b"1")
+    store.wait([key + "/go"])
 
 
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -236,11 +333,38 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def _shared_native(t: torch.Tensor, group):
+    """DDP's native communicator when the job runs on torch's process group: collectives on GPU tensors take it,
+    so torch's own (lazily built) RCCL communicator is never created -- one communicator per rank."""
+    if t.is_cuda and group is None:
+        from .native_comm import shared
+
+        return shared()
+    return None
+
+
+def all_reduce_max(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place maximum over ranks (benchmark timing: the slowest rank's wall time)."""
+    if _NATIVE is not None:
+        _NATIVE.comm_for(t).all_reduce_max(t)
+    elif is_initialized():
+        nc = _shared_native(t, group)
+        if nc is not None:
+            nc.all_reduce_max(t)
+        else:
+            _tdist().all_reduce(t, op=_tdist().ReduceOp.MAX, group=group)
+    return t
+
+
 def broadcast(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if _NATIVE is not None:
         _NATIVE.comm_for(t).broadcast(t, src=src, async_op=False)
     elif is_initialized():
-        _tdist().broadcast(t, src=src, group=group)
+        nc = _shared_native(t, group)
+        if nc is not None:
+            nc.broadcast(t, src=src, async_op=False)
+        else:
+            _tdist().broadcast(t, src=src, group=group)
     return t
 
 

@@ -170,3 +170,70 @@ def p2p_allreduce(local_rank, world, port, out_dir):
                os.path.join(out_dir, "rank%d.pt" % local_rank))
     store.barrier("done", world)
     del peer, comm
+
+
+class OutOfOrderNet(torch.nn.Module):
+    """Registration order (last, first, mid) is NOT the backward order (last, mid, first): the reducer's first plan,
+    made from reverse registration order, is wrong and must be re-planned from the observed order."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.last = torch.nn.Linear(48, 6)
+        self.first = torch.nn.Linear(20, 64)
+        self.mid = torch.nn.Linear(64, 48)
+        self.unused = torch.nn.Linear(3, 3)         # never touched by forward: reduced as zeros
+
+    def forward(self, x):
+        return self.last(torch.relu(self.mid(torch.relu(self.first(x)))))
+
+
+def ddp_native_reducer(local_rank, world, port, out_dir):
+    """The C++ BucketReducer over the host backend (TcpStore + worker thread) at world >= 2: chunked buckets,
+    re-planning from the observed ready order, an unused parameter, three optimizer steps."""
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+
+    _init(local_rank, world, port, "native")
+    model = OutOfOrderNet()
+    ddp = DistributedDataParallel(model, bucket_cap_mb=0.008, first_bucket_mb=0.001, last_bucket_mb=0.0,
+                                  chunk_mb=0.004, collective_timeout_s=30.0)
+    summary0 = ddp.comm_summary()
+    plan0 = [list(b.spec.param_ids) for b in ddp.arena.buckets]
+    opt = FusedSGD(ddp.parameters(), lr=0.05, momentum=0.9)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 4 * world, 20, generator=g)
+    t = torch.randn(3, 4 * world, 6, generator=g)
+    grads = []
+    for it in range(3):
+        xs = x[it, local_rank * 4:(local_rank + 1) * 4]
+        ts = t[it, local_rank * 4:(local_rank + 1) * 4]
+        loss = ((ddp(xs) - ts) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
+        opt.step()
+    torch.save({"grads": grads, "params": {n: p.detach().clone() for n, p in model.named_parameters()},
+                "summary0": summary0, "summary": ddp.comm_summary(), "plan0": plan0,
+                "plan": [list(b.spec.param_ids) for b in ddp.arena.buckets], "replans": ddp.replans},
+               os.path.join(out_dir, "rank%d.pt" % local_rank))
+    _finish()
+
+
+def reducer_hang(local_rank, world, port):
+    """Rank 1 stops calling all-reduce (it skips a backward and idles); rank 0's watchdog must abort and fail the
+    rank within the collective timeout instead of waiting forever."""
+    import time
+
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+
+    _init(local_rank, world, port, "native")
+    model = OutOfOrderNet()
+    ddp = DistributedDataParallel(model, collective_timeout_s=2.0, replan=False)
+    x = torch.randn(4, 20)
+    ddp(x).sum().backward()                  # a healthy step first
+    if local_rank == 1:
+        time.sleep(60)                       # never calls all-reduce again (the supervisor ends it)
+        return
+    ddp(x).sum().backward()                  # rank 0: blocks in finalize until the watchdog fires
+    time.sleep(60)

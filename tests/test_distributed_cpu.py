@@ -84,6 +84,65 @@ def test_native_store_rendezvous_and_host_collectives(tmp_path):
     assert sorted(d["n"] for d in rs) in ([1, 3], [2, 3])
 
 
+def test_native_store_shutdown_is_clean_every_time(tmp_path):
+    """Round-1 failure: rank 0 destroyed the store while rank 1's last barrier reply was unread (3 of 4 runs)."""
+    for i in range(6):
+        d = tmp_path / str(i)
+        d.mkdir()
+        t0 = time.time()
+        launch.spawn(W.store_ops, 2, (2, _port(), str(d)))
+        assert time.time() - t0 < 30
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_reducer_on_host_backend_chunks_replans_and_matches_oracle(tmp_path, world):
+    """The same C++ state machine that drives RCCL, over host memory at world 2 and 4 (csrc/comm/reducer_core.cpp)."""
+    launch.spawn(W.ddp_native_reducer, world, (world, _port(), str(tmp_path)))
+    rs = [torch.load(tmp_path / ("rank%d.pt" % r), weights_only=True) for r in range(world)]
+    r0 = rs[0]
+    assert r0["summary0"]["reducer"] == "c++" and r0["summary0"]["ranks"] == world
+    assert r0["summary0"]["buckets"] >= 3
+    # the big weights exceed chunk_mb: more collectives than buckets
+    assert r0["summary0"]["collectives"] == 0 and r0["summary"]["collectives"] > 2 * r0["summary"]["buckets"]
+    # re-planned once, from the observed order: `last.*` is ready first although it was registered first
+    assert r0["replans"] == 1 and r0["plan"] != r0["plan0"]
+    names = [n for n, _ in W.OutOfOrderNet().named_parameters()]
+    flat = [names[i] for b in r0["plan"] for i in b]
+    assert flat[:2] == ["last.bias", "last.weight"] or flat[:2] == ["last.weight", "last.bias"]
+    assert flat.index("mid.weight") < flat.index("first.weight") < flat.index("unused.weight")
+    for r in rs[1:]:
+        assert r["plan"] == r0["plan"] and r["replans"] == 1
+        for n in r0["params"]:
+            assert torch.equal(r["params"][n], r0["params"][n]), n
+    # oracle: one process, whole batch, torch SGD
+    model = W.OutOfOrderNet()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 4 * world, 20, generator=g)
+    t = torch.randn(3, 4 * world, 6, generator=g)
+    for it in range(3):
+        opt.zero_grad()
+        ((model(x[it]) - t[it]) ** 2).mean().backward()
+        for n, p in model.named_parameters():
+            want = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert torch.allclose(r0["grads"][it][n], want, rtol=1e-4, atol=1e-6), (it, n)
+        for p in model.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        opt.step()
+    for n, p in model.named_parameters():
+        assert torch.allclose(r0["params"][n], p, rtol=1e-4, atol=1e-6), n
+
+
+def test_watchdog_fails_the_rank_when_a_peer_stops_calling_all_reduce():
+    t0 = time.time()
+    with pytest.raises(launch.ProcessFailure) as e:
+        launch.spawn(W.reducer_hang, 2, (2, _port()))
+    assert e.value.local_rank == 0 and e.value.exitcode != 0
+    assert "reducer failed" in e.value.tb or e.value.exitcode == 86
+    assert time.time() - t0 < 40
+
+
 @pytest.mark.parametrize("delay,backend", [(False, "gloo"), (True, "gloo"), (False, "native")])
 def test_ddp_matches_single_process_on_full_batch(tmp_path, delay, backend):
     world = 2
