@@ -12,6 +12,8 @@ zero_grad + backward + SGD step in the timed region, images/sec = batch * steps 
 """
 import argparse
 import json
+import sys
+import threading
 import time
 
 import torch
@@ -72,6 +74,16 @@ def main():
     ap.add_argument("--foreach", type=int, default=1)
     ap.add_argument("--miopen-benchmark", type=int, default=1)
     args = ap.parse_args()
+    progress = {"phase": "init", "step": 0}
+
+    def heartbeat():          # MIOpen's first-call kernel search is silent for minutes; the GPU runner kills silent jobs
+        t0 = time.time()
+        while not progress.get("done"):
+            time.sleep(30)
+            print("[torch_baseline] %4.0fs %s step %d" % (time.time() - t0, progress["phase"], progress["step"]),
+                  file=sys.stderr, flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
     dev = torch.device("cuda", 0)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)       # the reference sets this (imagenet_ddp.py:158)
     torch.manual_seed(1234)
@@ -109,14 +121,18 @@ def main():
         opt.step()
         return loss
 
+    progress["phase"] = "warmup"
     for i in range(args.warmup):
         loss = step(i)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        progress["step"] = i + 1
+    progress["phase"] = "timed"
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    progress["done"] = True
     print(json.dumps({
         "metric": "images/sec ResNet-50 training, STOCK PyTorch-ROCm (torch.nn + autocast + channels_last + torch.optim.SGD)",
         "value": round(args.batch_size * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1,

@@ -29,9 +29,11 @@ PYBIND11_MODULE(_C, m) {
            int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
            int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream,
            uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu, int groups, long a_gstride, long b_gstride,
-           long c_gstride, int stats_ld, uintptr_t r_mask) {
+           long c_gstride, int stats_ld, uintptr_t r_mask, uintptr_t a_scale, uintptr_t a_shift) {
           IgemmParams p;
           p.r_mask = ptr<const uint8_t>(r_mask);
+          p.a_scale = ptr<const float>(a_scale);
+          p.a_shift = ptr<const float>(a_shift);
           p.groups = groups; p.a_gstride = a_gstride; p.b_gstride = b_gstride; p.c_gstride = c_gstride;
           p.stats_ld = stats_ld;
           p.bn_x = ptr<const void>(bn_x);
@@ -60,8 +62,11 @@ PYBIND11_MODULE(_C, m) {
         py::arg("OWF"), py::arg("OSY"), py::arg("OSX"), py::arg("OY0"), py::arg("OX0"), py::arg("flags"),
         py::arg("dtype"), py::arg("out_dtype"), py::arg("stream"), py::arg("bn_x") = 0, py::arg("bn_z") = 0,
         py::arg("bn_coef") = 0, py::arg("bn_relu") = 0, py::arg("groups") = 1, py::arg("a_gstride") = 0,
-        py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0, py::arg("r_mask") = 0);
+        py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0, py::arg("r_mask") = 0,
+        py::arg("a_scale") = 0, py::arg("a_shift") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
+  m.attr("IGEMM_AXF") = (int)kIgemmAxf;
+  m.def("igemm_axf_ok", &igemm_axf_ok);
   m.attr("IGEMM_ROW3") = (int)kIgemmRow3;
   m.def("igemm_set_row3", &igemm_set_row3);
   m.def("igemm_set_nt_store", &igemm_set_nt_store);
@@ -83,8 +88,10 @@ PYBIND11_MODULE(_C, m) {
   m.def("wgrad",
         [](uintptr_t dY, uintptr_t X, uintptr_t slab, uintptr_t taps, int M, int N, int Cred, int ntaps, int ldy,
            int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int taps_zero, int dtype,
-           uintptr_t stream, int groups, long y_gstride, long x_gstride) {
+           uintptr_t stream, int groups, long y_gstride, long x_gstride, uintptr_t x_scale, uintptr_t x_shift) {
           WgradParams p;
+          p.x_scale = ptr<const float>(x_scale);
+          p.x_shift = ptr<const float>(x_shift);
           p.groups = groups; p.y_gstride = y_gstride; p.x_gstride = x_gstride; p.slab_rows = groups * N;
           p.taps_zero = taps_zero;
           p.dY = ptr<const void>(dY);
@@ -101,7 +108,8 @@ PYBIND11_MODULE(_C, m) {
         py::arg("dY"), py::arg("X"), py::arg("slab"), py::arg("taps"), py::arg("M"), py::arg("N"), py::arg("Cred"),
         py::arg("ntaps"), py::arg("ldy"), py::arg("ldx"), py::arg("IH"), py::arg("IW"), py::arg("SY"), py::arg("SX"),
         py::arg("OH"), py::arg("OW"), py::arg("splits"), py::arg("pps"), py::arg("taps_zero"), py::arg("dtype"),
-        py::arg("stream"), py::arg("groups") = 1, py::arg("y_gstride") = 0, py::arg("x_gstride") = 0);
+        py::arg("stream"), py::arg("groups") = 1, py::arg("y_gstride") = 0, py::arg("x_gstride") = 0,
+        py::arg("x_scale") = 0, py::arg("x_shift") = 0);
   m.def("slab_reduce", [](uintptr_t slab, int splits, long n, uintptr_t out, int out_dtype, float beta, uintptr_t s) {
     slab_reduce_launch(ptr<const float>(slab), splits, n, ptr<void>(out), out_dtype, beta, st(s));
   });

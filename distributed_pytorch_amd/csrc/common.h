@@ -71,6 +71,49 @@ template <typename T> struct Vec16 {
   }
 };
 
+// ---- relu(scale * x + shift) on one 16-byte chunk (BatchNorm + ReLU applied while an operand tile is staged) -----
+// Bit-identical to the stand-alone bn_apply pass: fp32 fma, one rounding to T, ReLU.  The bf16 version is written
+// for the VALU budget of the GEMM loops that host it: packed fp32 fma (v_pk_fma_f32), packed convert
+// (v_cvt_pk_bf16_f32) and the ReLU as a packed signed-16-bit max with zero on the ROUNDED pair (a negative bf16 has
+// its sign bit set, i.e. is a negative int16; -0.0 becomes +0.0 like fmaxf(x, 0) does) -- 5 VALU ops per two elements.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bn_relu_pair_bf16(uint32_t w, f32x2_t sc, f32x2_t sh) {
+  f32x2_t x;
+  x.x = __uint_as_float(w << 16);
+  x.y = __uint_as_float(w & 0xffff0000u);
+  const f32x2_t y = x * sc + sh;
+  const bf16x2_t p = __builtin_convertvector(y, bf16x2_t);
+  s16x2_t v;
+  __builtin_memcpy(&v, &p, 4);
+  const s16x2_t zero = {0, 0};
+  v = __builtin_elementwise_max(v, zero);
+  uint32_t r;
+  __builtin_memcpy(&r, &v, 4);
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 bn_relu_chunk(const uint4& raw, const float (&sc)[16 / sizeof(T)],
+                                               const float (&sh)[16 / sizeof(T)]) {
+  if constexpr (sizeof(T) == 2 && TypeInfo<T>::kCode == kBF16) {
+    uint4 r;
+    r.x = bn_relu_pair_bf16(raw.x, f32x2_t{sc[0], sc[1]}, f32x2_t{sh[0], sh[1]});
+    r.y = bn_relu_pair_bf16(raw.y, f32x2_t{sc[2], sc[3]}, f32x2_t{sh[2], sh[3]});
+    r.z = bn_relu_pair_bf16(raw.z, f32x2_t{sc[4], sc[5]}, f32x2_t{sh[4], sh[5]});
+    r.w = bn_relu_pair_bf16(raw.w, f32x2_t{sc[6], sc[7]}, f32x2_t{sh[6], sh[7]});
+    return r;
+  } else {
+    Vec16<T> v;
+    v.raw = raw;
+#pragma unroll
+    for (int j = 0; j < (int)(16 / sizeof(T)); ++j) v.set(j, fmaxf(v.get(j) * sc[j] + sh[j], 0.f));
+    return v.raw;
+  }
+}
+
 // ---- fast unsigned division by a runtime constant (host computes the magic) ---------------
 struct FastDiv {
   uint32_t d, magic, shift;

@@ -55,6 +55,34 @@ template <> struct Mma<float> {
   }
 };
 
+constexpr int kAxfMaxCred = 2048;     // LDS table: 8 bytes per reduction channel
+
+// ---- BatchNorm + ReLU applied while the A tile is staged (kIgemmAxf) ---------------------------------------------
+// The workgroup keeps (scale, shift) of every reduction channel in LDS, laid out per 16-byte chunk of the activation:
+// [VEC scales][VEC shifts] (64 bytes for the 16-bit types), so the thread that stages chunk q reads four b128.
+// The value written to LDS is bit-identical to what the stand-alone bn_apply pass stores: fp32 fma, ReLU, one
+// rounding to T.  Out-of-image taps are masked AFTER this (the padding of the activation is zero, not relu(shift)).
+template <typename T>
+__device__ __forceinline__ void axf_fill_table(float* tab, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, int cred, int tid, int nthreads) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  for (int c = tid; c < cred; c += nthreads) {
+    float* t = tab + (c / VEC) * (2 * VEC) + (c % VEC);
+    t[0] = scale[c];
+    t[VEC] = shift[c];
+  }
+}
+template <typename T>
+__device__ __forceinline__ uint4 axf_apply(const uint4& raw, const float* tab_q) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  static_assert(VEC == 8, "apply-on-load is instantiated for the 16-bit types only");
+  const float4* t4 = reinterpret_cast<const float4*>(tab_q);
+  const float4 s0 = t4[0], s1 = t4[1], h0 = t4[2], h1 = t4[3];
+  const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  return bn_relu_chunk<T>(raw, sc, sh);
+}
+
 // ---- epilogue shared by both main loops: registers -> LDS tile [pixel][channel] -> 16-byte global
 // stores (+ bias, ReLU, fused accumulate, BatchNorm partial statistics).  All waves must be past their
 // last read of the staging buffers (barrier) and have no LDS-DMA in flight when they enter.
@@ -253,8 +281,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
 
 // BM: pixel rows per block, BN: output channels per block, BKB: bytes of K per row per K tile.
 // 256 threads = 2 (pixel) x 2 (channel) waves.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB, bool AXF = false>
 __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
+  static_assert(!AXF || (ALIGNED && sizeof(T) == 2), "apply-on-load: aligned 16-bit problems");
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
   constexpr int CPR = BKB / 16;          // 16-byte chunks per tile row
@@ -313,6 +342,13 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   }
 
   uint4 ra[A_IT], rb[B_IT];
+  // AXF: (scale, shift) table behind the two staging buffers; chunk index of the K tile held in ra[]
+  float* axf_tab = reinterpret_cast<float*>(smem + 2 * STAGE);
+  int axf_q = 0;
+  if constexpr (AXF) {
+    axf_fill_table<T>(axf_tab, p.a_scale, p.a_shift, p.Cred, tid, 256);
+    __syncthreads();
+  }
   const int kpt = ALIGNED ? p.Cred / BK : 1;           // K tiles per tap
   const int cpt = p.Cred / VEC;                        // chunks per tap
   const int nk = ALIGNED ? p.ntaps * kpt : (p.ntaps * cpt + CPR - 1) / CPR;
@@ -350,6 +386,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
     if (ALIGNED) {
       if (lt_kc == 0) set_tap(lt_tap);
       const int c0 = lt_kc * BK;
+      if constexpr (AXF) axf_q = lt_kc * CPR + ch;
       const char* Ak = Ag + (size_t)c0 * sizeof(T);
       const char* Bk = Bg + (kb_tap + c0) * sizeof(T);
 #pragma unroll
@@ -395,6 +432,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
     for (int i = 0; i < A_IT; ++i) {
       const int row = (tid + i * 256) / CPR;
       uint4 v = ra[i];
+      if constexpr (AXF) v = axf_apply<T>(v, axf_tab + axf_q * (32 / (int)sizeof(T)));
       v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
       *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
     }
@@ -456,8 +494,9 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 // Needs: taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (same x0 for all groups), SX == 1, the output
 // grid as wide as the gathered image, Cred % BK == 0, operands addressable with 32 bits.
 // One LDS stage (the next stage waits in registers): 41 KB for 128x128x64B, three workgroups per CU.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB, bool AXF = false>
 __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams p) {
+  static_assert(!AXF || sizeof(T) == 2, "apply-on-load: 16-bit problems");
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
   constexpr int CPR = BKB / 16;
@@ -536,6 +575,12 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
   uint32_t aoff[A_IT], amask[A_IT];
   size_t kb_tap[3] = {0, 0, 0};
   int lt_g = 0, lt_kc = 0;
+  float* axf_tab = reinterpret_cast<float*>(smem + (AR + 3 * BN) * LDR);   // behind the stage
+  int axf_q = 0;
+  if constexpr (AXF) {
+    axf_fill_table<T>(axf_tab, p.a_scale, p.a_shift, p.Cred, tid, 256);
+    __syncthreads();
+  }
   auto set_group = [&](int g) {
     const int dy = __builtin_amdgcn_readfirstlane(p.taps[9 * g]);
 #pragma unroll
@@ -552,6 +597,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
   auto load_stage = [&]() {
     if (lt_kc == 0) set_group(lt_g);
     const int c0 = lt_kc * BK;
+    if constexpr (AXF) axf_q = lt_kc * CPR + ch;
     const char* Ak = Ag + (size_t)c0 * sizeof(T);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + aoff[i]);
@@ -572,6 +618,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
       const int row = (tid + i * 256) / CPR;
       if (row < AR) {
         uint4 v = ra[i];
+        if constexpr (AXF) v = axf_apply<T>(v, axf_tab + axf_q * (32 / (int)sizeof(T)));
         v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
         *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
       }
@@ -632,19 +679,24 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
   igemm_epilogue<TOut, BM, BN, BNB>(p, acc, smem, m0, n0, mt);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB = false>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB = false, bool AXF = false>
 void launch_row3(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + 2 + 3 * BN) * LDR;
   constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
   constexpr int red_bytes = 4 * 2 * BN * 4;
-  constexpr int lds = stage_bytes > epi_bytes ? (stage_bytes > red_bytes ? stage_bytes : red_bytes)
-                                              : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
-  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB>;
+  constexpr int lds0 = stage_bytes > epi_bytes ? (stage_bytes > red_bytes ? stage_bytes : red_bytes)
+                                               : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
+  int lds = lds0;
+  if (AXF) {            // (scale, shift) table behind the stage
+    if (p.Cred > kAxfMaxCred) throw std::invalid_argument("igemm: apply-on-load supports at most 2048 reduction channels");
+    if (lds < stage_bytes + 8 * p.Cred) lds = stage_bytes + 8 * p.Cred;
+  }
+  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB, AXF>;
   static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
+  if (!attr_done && lds0 + 8 * kAxfMaxCred > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds0 + 8 * kAxfMaxCred));
     attr_done = true;
   }
   const long tiles = (long)ceil_div(p.M, BM) * ceil_div(p.N, BN);
@@ -878,20 +930,25 @@ void launch_glds(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)p.groups), dim3(256), lds, stream, p);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB = false>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB = false, bool AXF = false>
 void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + BN) * LDR;
   constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
   constexpr int red_bytes = 4 * 2 * BN * 4;
-  constexpr int max_lds = 2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes;
+  constexpr int axf_bytes = AXF ? 8 * kAxfMaxCred : 0;
+  constexpr int max_lds = 2 * stage_bytes + axf_bytes > epi_bytes ? 2 * stage_bytes + axf_bytes : epi_bytes;
   // a single K tile (1x1 convolutions with few input channels) needs no second staging buffer
   constexpr int BK = BKB / (int)sizeof(T), VEC = 16 / (int)sizeof(T), CPR = BKB / 16;
   const int nk = ALIGNED ? p.ntaps * (p.Cred / BK) : (p.ntaps * (p.Cred / VEC) + CPR - 1) / CPR;
   int lds = (nk > 1 ? 2 : 1) * stage_bytes;
+  if (AXF) {            // the (scale, shift) table sits behind BOTH staging buffers
+    if (p.Cred > kAxfMaxCred) throw std::invalid_argument("igemm: apply-on-load supports at most 2048 reduction channels");
+    lds = 2 * stage_bytes + 8 * p.Cred;
+  }
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED, BNB>;
+  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED, BNB, AXF>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -951,6 +1008,33 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
                       (double)p.N * p.ldb * ES < 4294967296.0;
   const bool aligned = p.Cred % (64 / ES) == 0 && fits32;
   const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
+  if (p.flags & kIgemmAxf) {
+    // forward convolution whose input is a BatchNorm + ReLU applied while the A tile is staged
+    if constexpr (EXT) {
+      if (aligned && !(p.flags & kIgemmBnBwd) && p.groups == 1) {
+        if ((p.flags & kIgemmRow3) && g_row3_mode != 0 && p.ntaps % 3 == 0 && p.SX == 1 && (int)p.div_ow.d == p.IW) {
+          const bool k128 = p.Cred % (128 / ES) == 0 && (g_row3_mode == 2 || (g_row3_mode < 0 && p.Cred * ES >= 1024));
+          if (p.N > 64) {
+            if (k128) launch_row3<T, TOut, 128, 128, 128, 2, false, true>(p, stream);
+            else launch_row3<T, TOut, 128, 128, 64, 3, false, true>(p, stream);
+          } else {
+            if (k128) launch_row3<T, TOut, 128, 64, 128, 3, false, true>(p, stream);
+            else launch_row3<T, TOut, 128, 64, 64, 4, false, true>(p, stream);
+          }
+          return;
+        }
+        // every AXF kernel has 128 pixel rows per tile, which is what igemm_stats_rows promised for cfg 0..9
+        if (kCfgs[cfg].bm != 128) throw std::invalid_argument("igemm: apply-on-load with a forced 256-row tile");
+        switch (cfg <= 3 ? cfg : choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, false)) {
+          case 0: launch_cfg<T, TOut, 128, 128, 128, 2, true, false, true>(p, stream); return;
+          case 1: launch_cfg<T, TOut, 128, 64, 128, 2, true, false, true>(p, stream); return;
+          case 2: launch_cfg<T, TOut, 128, 128, 64, 2, true, false, true>(p, stream); return;
+          default: launch_cfg<T, TOut, 128, 64, 64, 2, true, false, true>(p, stream); return;
+        }
+      }
+    }
+    throw std::invalid_argument("igemm: apply-on-load needs a dense 16-bit problem with 64-byte aligned channels");
+  }
   if constexpr (EXT) {
     if ((p.flags & kIgemmRow3) && aligned && g_force_cfg < 0 && g_row3_mode != 0 &&
         p.ntaps % 3 == 0 && p.SX == 1 && (int)p.div_ow.d == p.IW) {
@@ -1043,6 +1127,8 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
   if ((long)p.M >= (1l << 31) || p.ntaps <= 0) throw std::invalid_argument("igemm: bad problem size");
   if (p.stats != nullptr && out_dtype != dtype)
     throw std::invalid_argument("igemm: stats need out dtype == in dtype");
+  if ((p.flags & kIgemmAxf) && (p.a_scale == nullptr || p.a_shift == nullptr))
+    throw std::invalid_argument("igemm: apply-on-load needs a_scale and a_shift");
   if (p.flags & kIgemmBnBwd) {
     if (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr ||
         ((p.bn_relu == 1 || p.bn_relu == 3) && p.bn_z == nullptr))
@@ -1057,6 +1143,13 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
   else if (dtype == kF16 && out_dtype == kF32) dispatch_tiles<f16_t, float>(p, stream);
   else throw std::invalid_argument("igemm: unsupported dtype combination");
   DPA_CHECK_HIP(hipGetLastError());
+}
+
+bool igemm_axf_ok(long NB, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups) {
+  if (dtype == kF32 || dtype != out_dtype || groups > 1) return false;
+  const int es = 2;
+  if (Cred % (64 / es) != 0 || Cred > kAxfMaxCred) return false;
+  return (double)(NB + 1) * IH * IW * lda * es < 4294967296.0 && (double)N * ldb * es < 4294967296.0;
 }
 
 int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype) {

@@ -8,7 +8,11 @@ namespace dpa {
 // ------------------------------------------------------------------------------ igemm.hip
 // kIgemmRow3: the caller guarantees taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (one x0 for all
 // groups): 3x3-like stride-1 "same" convolutions may then run the filter-row kernel (one staged A tile per 3 taps)
-enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16 };
+// kIgemmAxf: A is the RAW input z of a training-mode BatchNorm + ReLU; the kernel applies a = relu(a_scale[c] * z +
+// a_shift[c]) while it stages the A tile (the normalised activation is never written to memory).  16-bit dense
+// problems with 64-byte aligned reduction channels only (igemm_axf_ok).
+enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16,
+                        kIgemmAxf = 32 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -26,6 +30,8 @@ struct IgemmParams {
   const void* bn_z;    // BN output (bn_relu == 1)
   const float* bn_coef;  // [4][N]: mean, invstd, scale, shift
   int bn_relu;
+  const float* a_scale = nullptr;   // kIgemmAxf: [Cred] each
+  const float* a_shift = nullptr;
   // grouped convolution: grid.y = group; a group's slice starts g * stride ELEMENTS into each operand (groups
   // <= 1: dense).  N, Cred are per group; bias / statistics are indexed by the global channel g * c_gstride + n,
   // stats_ld is the slab's row width (all groups; 0 = N).
@@ -42,6 +48,8 @@ struct IgemmParams {
   FastDiv div_ohow, div_ow;          // (sub)grid OH*OW and OW
 };
 void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
+// whether a launch of this shape can take kIgemmAxf (the caller materialises the activation otherwise)
+bool igemm_axf_ok(long NB, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups);
 int igemm_tile_m(int dtype);
 // rows of the per-tile BatchNorm statistics slab the launch for this problem will write
 int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype);
@@ -70,6 +78,9 @@ struct WgradParams {
   long y_gstride = 0, x_gstride = 0;
   int slab_rows = 0;   // rows of one split's slab = groups * N
   int taps_zero;       // every tap is (0, 0): a 1x1 convolution without padding (enables the linear fast path)
+  // X is the raw input z of a BatchNorm + ReLU: the kernel stages relu(x_scale[c] * z + x_shift[c]) (16-bit, dense)
+  const float* x_scale = nullptr;
+  const float* x_shift = nullptr;
   FastDiv div_ohow, div_ow;
 };
 void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);

@@ -35,8 +35,11 @@ __device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
 // LIN: 1x1 / stride 1 / no padding and both operands < 4 GiB (host checked): the im2col row of pixel m is row m
 // of X, so both operands are walked with 32-bit byte offsets that advance by a constant per K tile -- no
 // divisions, no 64-bit address arithmetic in the loop (PMC counters showed the generic gather issue bound).
-template <typename T, int BI, int BJ, int KB, int WI, int WJ, bool LIN, int PF>
+// XF: X is the raw input z of a BatchNorm + ReLU; the staged operand is relu(x_scale[c] * z + x_shift[c]).  A thread
+// stages one fixed 16-byte chunk column for the whole kernel, so its 8 (scale, shift) pairs live in registers.
+template <typename T, int BI, int BJ, int KB, int WI, int WJ, bool LIN, int PF, bool XF = false>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p) {
+  static_assert(!XF || sizeof(T) == 2, "apply-on-load: 16-bit problems");
   constexpr int NT = 64 * WI * WJ;                     // WI x WJ waves, each owns a (BI/WI) x (BJ/WJ) sub-tile
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BKP = KB / (int)sizeof(T);             // pixels per K tile (KB bytes of K per column)
@@ -80,6 +83,14 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
     qc = kcol - t * p.Cred;
     qdy = p.taps[3 * t + 0];
     qdx = p.taps[3 * t + 1];
+  }
+  float xsc[XF ? VEC : 1], xsh[XF ? VEC : 1];
+  if constexpr (XF) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      xsc[j] = qok ? p.x_scale[qc + j] : 0.f;
+      xsh[j] = qok ? p.x_shift[qc + j] : 0.f;
+    }
   }
 
   // two register sets: tiles kt+1 and kt+2 are in flight while tile kt is consumed from LDS (one tile ahead
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
     for (int i = 0; i < Q_IT; ++i) {
       const int row = (tid + i * NT) / CPQ;
       uint4 v = rq[S][i];
+      if constexpr (XF) v = bn_relu_chunk<T>(v, xsc, xsh);   // as bn_apply stores it; padding is masked afterwards
       v.x &= qmask[S][i]; v.y &= qmask[S][i]; v.z &= qmask[S][i]; v.w &= qmask[S][i];
       *reinterpret_cast<uint4*>(sq + row * LDQ + cq * 16) = v;
     }
@@ -346,8 +358,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-template <typename T, int BI, int BJ, int KB, int WI = 2, int WJ = 2, int PF = 1>
-void launch_cfg(const WgradParams& p, hipStream_t stream) {
+template <typename T, int BI, int BJ, int KB, int WI, int WJ, int PF, bool XF>
+void launch_cfg_x(const WgradParams& p, hipStream_t stream) {
   constexpr int BKP = KB / (int)sizeof(T);
   constexpr int lds = 2 * BKP * ((BI + BJ) * (int)sizeof(T) + 128);
   const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
@@ -358,18 +370,29 @@ void launch_cfg(const WgradParams& p, hipStream_t stream) {
                    (double)p.M * p.ldy * es < 4294967296.0 && (double)nb * p.IH * p.IW * p.ldx * es < 4294967296.0;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF>),
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF, XF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF>),
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF, XF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
   if (lin)
-    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF>), dim3((unsigned)blocks, (unsigned)p.groups),
+    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, true, PF, XF>), dim3((unsigned)blocks, (unsigned)p.groups),
                        dim3(64 * WI * WJ), lds, stream, p);
   else
-    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF>), dim3((unsigned)blocks, (unsigned)p.groups),
+    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF, XF>), dim3((unsigned)blocks, (unsigned)p.groups),
                        dim3(64 * WI * WJ), lds, stream, p);
+}
+
+template <typename T, int BI, int BJ, int KB, int WI = 2, int WJ = 2, int PF = 1>
+void launch_cfg(const WgradParams& p, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    if (p.x_scale != nullptr) {
+      launch_cfg_x<T, BI, BJ, KB, WI, WJ, PF, true>(p, stream);
+      return;
+    }
+  }
+  launch_cfg_x<T, BI, BJ, KB, WI, WJ, PF, false>(p, stream);
 }
 
 // Tile configurations (output channels x im2col columns x bytes of pixels per K tile); picked per
@@ -457,6 +480,8 @@ void wgrad_launch(const WgradParams& p_in, int dtype, hipStream_t stream) {
   if (p.N % vec != 0 || p.Cred % vec != 0 || p.ldy % vec != 0 || p.ldx % vec != 0)
     throw std::invalid_argument("wgrad: channel counts / strides must be multiples of 16 bytes");
   if (p.Ktot != p.ntaps * p.Cred) throw std::invalid_argument("wgrad: Ktot != ntaps*Cred");
+  if ((p.x_scale != nullptr) != (p.x_shift != nullptr) || (p.x_scale != nullptr && (dtype == kF32 || p.groups > 1)))
+    throw std::invalid_argument("wgrad: apply-on-load needs scale AND shift, a 16-bit dtype and a dense problem");
   if ((long)p.splits * p.pix_per_split < p.M) throw std::invalid_argument("wgrad: splits do not cover M");
   {
     const int bkp = kWCfgs[choose_wcfg(p.M, p.N, p.Ktot)].kb / (dtype == kF32 ? 4 : 2);

@@ -51,7 +51,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         # `identity` aliases x: its gradient is added inside conv1's dgrad epilogue
-        out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True)
+        # bn1 + ReLU are deferred: conv2 applies them while it stages its input tiles (nothing is written in between)
+        out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True, defer=True)
         if self.downsample is not None:
             identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer=True)
         return conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=identity)
@@ -75,8 +76,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         # `identity` aliases x: its gradient is added inside conv1's dgrad epilogue
-        out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True)
-        out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        # bn1 / bn2 + ReLU are deferred to the convolution that consumes them (applied on load in fprop and wgrad):
+        # the two normalised activations of a bottleneck are never written to memory
+        out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True, defer=True)
+        out = conv_bn_act(out, self.conv2, self.bn2, relu=True, defer=True)
         if self.downsample is not None:
             identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)

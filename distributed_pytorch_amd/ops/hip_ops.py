@@ -233,11 +233,15 @@ def _conv_out(i, k, s, p):
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
            scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False,
-           accum_mask=None):
+           accum_mask=None, axf=None):
     """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
     ``row3``: the tap table is sorted into filter rows (dy, dx ascending, three taps per row): stride-1 "same"
     convolutions may use the filter-row kernel (one staged activation tile per three taps)."""
     flags = (C().IGEMM_RELU if relu else 0) | (C().IGEMM_ROW3 if row3 else 0)
+    a_scale = a_shift = 0
+    if axf is not None:                 # coef[4][Cred] of the BatchNorm + ReLU applied while A is staged
+        flags |= C().IGEMM_AXF
+        a_scale, a_shift = axf[2].data_ptr(), axf[3].data_ptr()
     gargs = (1, 0, 0, 0, 0) if groups is None else groups
     bn_x = bn_z = bn_coef = bn_relu = 0
     if bnred is not None:               # (bn input, bn output or None, coef[4][N], relu mode)
@@ -249,7 +253,8 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
         OHF, OWF, OSY, OSX, OY0, OX0 = scatter
     C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
-              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs, _p(accum_mask))
+              _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs, _p(accum_mask),
+              a_scale, a_shift)
 
 
 def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
@@ -286,7 +291,11 @@ def _deliver(param, g):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip, bnsrc=None):
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip, bnsrc=None,
+                axf=None):
+        # axf: x is the RAW input of a training-mode BatchNorm + ReLU (a "deferred" BN output) and `axf` that BN's
+        # coefficient table: forward and the weight gradient apply relu(scale * x + shift) while they stage the
+        # operand, the normalised activation is never written (profiles/r2_notes.md)
         x_in = x
         x = x if x.is_contiguous() else x.contiguous()
         NB, IH, IW, Cx = x.shape
@@ -310,7 +319,8 @@ class _ConvFn(torch.autograd.Function):
         if bias is not None:
             bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
         _igemm(x, wc, y, bias_f, stats, taps, M, K, Cx, R * S, Cx, R * S * Cx, K, IH, IW, sh, sw, OH, OW,
-               relu=relu, dtype=x.dtype, out_dtype=x.dtype, row3=(S == 3 and sw == 1 and pw == 1))
+               relu=relu, dtype=x.dtype, out_dtype=x.dtype, row3=(S == 3 and sw == 1 and pw == 1), axf=axf)
+        ctx.axf = axf
         ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
         # x is the output of a training-mode BatchNorm: the data-gradient epilogue can produce that BN's
@@ -343,8 +353,9 @@ class _ConvFn(torch.autograd.Function):
         if dy is None:                      # only the alias was used downstream
             if amask is not None:
                 dalias = apply_bit_mask(dalias, amask)
-            return dalias, None, None, None, None, None, None, None, None, None
+            return dalias, None, None, None, None, None, None, None, None, None, None
         x, weight, y = ctx.saved_tensors
+        axf = ctx.axf
         (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
         NB, IH, IW, Cx = x.shape
         K, Cw, R, S = weight.shape
@@ -365,7 +376,7 @@ class _ConvFn(torch.autograd.Function):
             side = side_stream(dy.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
+                dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw), axf=axf)
             dy.record_stream(side)
             x.record_stream(side)
             if dw is not None:              # handed back to autograd on the main stream
@@ -381,11 +392,11 @@ class _ConvFn(torch.autograd.Function):
         elif dalias is not None:
             dx = apply_bit_mask(dalias, amask) if amask is not None else dalias
         if ctx.needs_input_grad[1] and not wgrad_done:
-            dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw))
+            dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw), axf=axf)
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
             db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 # Fused BN-backward reduction in the data-gradient epilogue (DPA_FUSE_BN_BWD=0 disables).  First measured a wash
@@ -490,7 +501,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
     return dx
 
 
-def conv_wgrad(dy, x, weight, stride, padding):
+def conv_wgrad(dy, x, weight, stride, padding, axf=None):
     NB, IH, IW, Cx = x.shape
     K, Cw, R, S = weight.shape
     sh, sw = stride
@@ -503,7 +514,8 @@ def conv_wgrad(dy, x, weight, stride, padding):
     taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
     st = _stream()
     C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
-              sh, sw, OH, OW, splits, pps, 1 if (R * S == 1 and ph == 0 and pw == 0) else 0, _dt(dy), st)
+              sh, sw, OH, OW, splits, pps, 1 if (R * S == 1 and ph == 0 and pw == 0) else 0, _dt(dy), st,
+              1, 0, 0, axf[2].data_ptr() if axf is not None else 0, axf[3].data_ptr() if axf is not None else 0)
     gdtype = weight.dtype
     sink = grad_sink.sink_of(weight)
     if Cx == Cw and sink is not None and _flat_same_layout(sink.view, weight) \
@@ -534,10 +546,63 @@ def _slice_channels(src: torch.Tensor, dst: torch.Tensor, keep: int) -> None:
     C().transpose_ktc(tmp.data_ptr(), dst.data_ptr(), keep, 1, n, 0, _dt(dst), _stream())
 
 
+_AXF = os.environ.get("DPA_BN_APPLY_ON_LOAD", "1") == "1"
+# Apply-on-load re-does the BatchNorm arithmetic every time an activation element is staged: once per output-channel
+# tile and filter tap (row) in forward, once per output-channel tile and tap in the weight gradient.  Beyond this many
+# stagings per element the stand-alone bn_apply pass (one read + one write) is cheaper (profiles/r2_notes.md).
+_AXF_MAX_RED = float(os.environ.get("DPA_AXF_MAX_RED", "8"))
+
+
+def _axf_redundancy(K: int, R: int, S: int, stride) -> float:
+    ntile = (K + 127) // 128
+    row3 = S == 3 and stride[1] == 1
+    return ntile * (R * S / (3.0 if row3 else 1.0)) + ntile * R * S
+
+
+class _MaterializeFn(torch.autograd.Function):
+    """relu(scale * x + shift) of a deferred BatchNorm + ReLU for a consumer that cannot apply it on load.  The
+    BatchNorm's own backward recomputes the ReLU mask from x, so the gradient passes through unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, coef):
+        y = torch.empty_like(x)
+        Cc = x.shape[-1]
+        C().bn_apply(x.data_ptr(), 0, y.data_ptr(), x.numel() // Cc, Cc, _dt(x), coef[2].data_ptr(), coef[3].data_ptr(),
+                     1, _stream(), 0, 0, 0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def materialize(x: torch.Tensor) -> torch.Tensor:
+    """The normalised activation behind a deferred BatchNorm + ReLU output (identity for ordinary tensors)."""
+    coef = getattr(x, "_dpa_deferred_coef", None)
+    if coef is None:
+        return x
+    if not getattr(x, "_dpa_deferred_relu", False):
+        raise ValueError("a deferred activation-free BatchNorm output can only be the `residual` of another BatchNorm")
+    y = _MaterializeFn.apply(x, coef)
+    bn = getattr(x, "_dpa_bn", None)
+    if bn is not None:
+        y._dpa_bn = bn
+    return y
+
+
 def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad, skip=False):
     grad_sink.note_use(weight, bias)
+    axf = getattr(x, "_dpa_deferred_coef", None)
+    if axf is not None:
+        K, Cw = weight.shape[0], weight.shape[1]
+        NB, IH, IW, Cx = x.shape
+        ok = getattr(x, "_dpa_deferred_relu", False) and not skip and x.is_contiguous() and Cx == Cw \
+            and _axf_redundancy(K, weight.shape[2], weight.shape[3], stride) <= _AXF_MAX_RED \
+            and C().igemm_axf_ok(NB, IH, IW, Cx, K, Cx, weight.shape[2] * weight.shape[3] * Cx, _dt(x), _dt(x), 1)
+        if not ok:
+            x, axf = materialize(x), None
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
-                                    bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None))
+                                    bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None), axf)
     if alias is not None:
         # its gradient returns to _ConvFn.backward (and nowhere else): a BatchNorm that takes it as the residual may
         # hand back the UNMASKED gradient plus its ReLU bit mask instead of writing a masked copy
@@ -788,6 +853,7 @@ class _DepthwiseConvFn(torch.autograd.Function):
 
 def group_conv2d(x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad=True):
     grad_sink.note_use(weight, bias)
+    x = materialize(x)
     K, Cg, R, S = weight.shape
     if _DW_DIRECT and groups == K and Cg == 1 and x.shape[-1] == K and R <= 7 and S <= 7 \
             and weight.dtype in (torch.float32, x.dtype):
@@ -896,6 +962,19 @@ class _BNFn(torch.autograd.Function):
                                  g32.data_ptr(), b32.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
                                  _p(nbt), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
                                  coef[3].data_ptr(), st)
+        if defer and relu == 1 and not act and residual is None:
+            # Deferred BN + ReLU: nothing is written either.  The consumer -- a dense convolution -- applies
+            # relu(scale * x + shift) while it stages its operand tiles, in forward and in its weight gradient
+            # (igemm kIgemmAxf / wgrad x_scale); backward is the ordinary one with the mask recomputed from x.
+            ctx.save_for_backward(x, None, weight, coef, count_dev)
+            ctx.bias_ref = bias
+            ctx.lazy_res = False
+            ctx.res_coef = None
+            ctx.cfg = (2, False, group, count)
+            _BNFn.last = _BnSrc(x, coef, 2, None)
+            _BNFn.deferred = coef
+            _BNFn.deferred_relu = True
+            return x.view(x.shape)
         if defer and not relu and not act and residual is None and world == 1:
             # Deferred: nothing is written.  The result is an alias of the raw input carrying this BN's (scale,
             # shift); the BatchNorm that takes it as `residual` applies them on the fly.  Backward is the normal one.
@@ -905,6 +984,7 @@ class _BNFn(torch.autograd.Function):
             ctx.cfg = (0, False, group, count)
             _BNFn.last = None
             _BNFn.deferred = coef
+            _BNFn.deferred_relu = False
             return x.view(x.shape)
         res_coef = getattr(residual, "_dpa_deferred_coef", None) if residual is not None else None
         if residual is not None and not residual.is_contiguous():
@@ -1175,9 +1255,11 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
         y = _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
                         running_var if training else None, num_batches_tracked if training else None,
                         float(momentum if momentum is not None else 0.1), float(eps), _act_code(relu), stats, group,
-                        bool(defer and _DEFER_BN and training and torch.is_grad_enabled()))
+                        bool(defer and training and torch.is_grad_enabled()
+                             and (_AXF if relu else _DEFER_BN)))
         if _BNFn.deferred is not None:
             y._dpa_deferred_coef = _BNFn.deferred
+            y._dpa_deferred_relu = _BNFn.deferred_relu
             _BNFn.deferred = None
         if _BNFn.last is not None and torch.is_grad_enabled():
             y._dpa_bn = _BNFn.last      # lets the consuming convolution fuse this BN's backward reduction

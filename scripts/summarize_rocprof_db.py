@@ -24,7 +24,7 @@ def main():
         os.path.basename(dbs[0]), steps, tot / 1e6 / steps))
     print("| kernel | calls/step | avg us | ms/step | % |")
     print("|---|---|---|---|---|")
-    for n, c, t in rows[:28]:
+    for n, c, t in rows[:int(os.environ.get("ROWS", "28"))]:
         n = n.replace("dpa::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:100]
         print("| `%s` | %.1f | %.1f | %.3f | %.1f |" % (n, c / steps, t / c / 1e3, t / 1e6 / steps, 100.0 * t / tot))
 

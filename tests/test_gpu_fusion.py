@@ -1,0 +1,104 @@
+"""BatchNorm + ReLU applied while the consuming convolution stages its operand (igemm kIgemmAxf / wgrad x_scale).
+
+Two checks per shape: (1) the fused chain is BIT-IDENTICAL to the unfused chain of the same HIP kernels (same values
+reach LDS, same accumulation order), forward and every gradient; (2) the fused chain matches an fp32 PyTorch
+reference of conv(relu(batch_norm(x))) fed the same rounded inputs."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from distributed_pytorch_amd.ops import functional as F  # noqa: E402
+from distributed_pytorch_amd.ops import hip_ops  # noqa: E402
+
+from _gpu_util import assert_close  # noqa: E402
+
+DEV = "cuda"
+
+AXF_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (4, 14, 14, 64, 64, 3, 1, 1),        # filter-row kernel, 64-byte K tiles, narrow N
+    (4, 14, 14, 64, 256, 1, 1, 0),       # 1x1 expansion (conv3 of a bottleneck)
+    (3, 15, 13, 128, 128, 3, 2, 1),      # stride-2 3x3 (first block of a stage): generic aligned gather, odd extents
+    (2, 9, 9, 512, 512, 3, 1, 1),        # filter-row kernel, 128-byte K tiles
+    (2, 7, 7, 512, 2048, 1, 1, 0),       # deep 1x1, 128-byte K tiles
+    (5, 9, 11, 96, 72, 3, 1, 1),         # Cin % 32 != 0 for bf16 -> not eligible: must fall back to the materialised path
+    (2, 12, 12, 32, 40, 3, 1, 1),        # smallest eligible channel count, Cout tail
+]
+
+
+def _chain(x, g, b, w, s, p, fused):
+    old, old_red = hip_ops._AXF, hip_ops._AXF_MAX_RED
+    hip_ops._AXF, hip_ops._AXF_MAX_RED = fused, 1e9         # every eligible shape, not only the ones the heuristic picks
+    try:
+        C = x.shape[-1]
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        a = F.batch_norm(x, g, b, rm, rv, nbt, True, 0.1, 1e-5, relu=True, defer=True)
+        deferred = getattr(a, "_dpa_deferred_coef", None) is not None
+        y = F.conv2d(a, w, None, s, p)
+        return y, deferred
+    finally:
+        hip_ops._AXF, hip_ops._AXF_MAX_RED = old, old_red
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", AXF_CASES)
+def test_bn_relu_apply_on_load(case, dtype):
+    N, H, W, Cin, Cout, k, s, p = case
+    torch.manual_seed(11)
+    x0 = (torch.randn(N, H, W, Cin, device=DEV) * 1.5 + 0.3).to(dtype)
+    g0 = torch.rand(Cin, device=DEV) + 0.5
+    b0 = torch.randn(Cin, device=DEV) * 0.3
+    w0 = (torch.randn(Cout, Cin, k, k, device=DEV) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        x = x0.clone().requires_grad_(True)
+        g, b, w = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        y, deferred = _chain(x, g, b, w, s, p, fused)
+        assert deferred == fused
+        torch.manual_seed(12)
+        gy = torch.randn_like(y.float()).to(dtype)
+        y.backward(gy)
+        res.append((y.detach(), x.grad, g.grad, b.grad, w.grad, gy))
+    (yf, dxf, dgf, dbf, dwf, gy), (yu, dxu, dgu, dbu, dwu, _) = res
+    assert torch.equal(yf, yu), "forward differs from the unfused kernels"
+    assert torch.equal(dwf, dwu), "weight gradient differs from the unfused kernels"
+    assert torch.equal(dxf, dxu) and torch.equal(dgf, dgu) and torch.equal(dbf, dbu), "BN backward differs"
+
+    # fp32 reference
+    xr = x0.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    wr = w0.to(dtype).float().requires_grad_(True)
+    ar = TF.relu(TF.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    # the kernels round the activation to the compute dtype before the MFMA: do the same (straight-through)
+    ar_q = ar + (ar.to(dtype).float() - ar).detach()
+    yr = TF.conv2d(ar_q, wr, None, s, p)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    assert_close(yf.permute(0, 3, 1, 2), yr, dtype, what="fprop")
+    assert_close(dwf, wr.grad, dtype, what="wgrad", scale=2)
+    # BN backward: the ReLU mask comes from the rounded activation and dy passes one more rounding
+    assert_close(dxf.permute(0, 3, 1, 2), xr.grad, dtype, what="dx", scale=4)
+    assert_close(dgf, gr.grad, dtype, what="dgamma", scale=4)
+    assert_close(dbf, br.grad, dtype, what="dbeta", scale=4)
+
+
+def test_deferred_bn_relu_into_grouped_conv_materialises():
+    """A consumer that cannot apply the BatchNorm on load (grouped convolution) gets the materialised activation."""
+    torch.manual_seed(5)
+    dtype = torch.bfloat16
+    x0 = torch.randn(2, 8, 8, 64, device=DEV).to(dtype)
+    g0, b0 = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.2
+    w0 = (torch.randn(64, 16, 3, 3, device=DEV) / 12).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for defer in (True, False):
+        x = x0.clone().requires_grad_(True)
+        g, b, w = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        a = F.batch_norm(x, g, b, rm, rv, None, True, 0.1, 1e-5, relu=True, defer=defer)
+        y = F.conv2d(a, w, None, 1, 1, groups=4)
+        y.float().square().sum().backward()
+        outs.append((y.detach(), x.grad, w.grad))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
