@@ -122,14 +122,18 @@ PYBIND11_MODULE(_C, m) {
   m.def("bn_fold_partials", [](uintptr_t partial, int nparts, int C, uintptr_t out, int nout, uintptr_t s) {
     bn_fold_partials_launch(ptr<const float>(partial), nparts, C, ptr<float>(out), nout, st(s));
   });
-  m.def("bn_finalize", [](uintptr_t partial, int nparts, int C, double count, uintptr_t count_dev, uintptr_t gamma,
-                          uintptr_t beta,
-                          float eps, float momentum, uintptr_t rm, uintptr_t rv, uintptr_t nbt, uintptr_t mean,
-                          uintptr_t invstd, uintptr_t scale, uintptr_t shift, uintptr_t s) {
-    bn_finalize_launch(ptr<const float>(partial), nparts, C, count, ptr<const float>(count_dev),
-                       ptr<const float>(gamma), ptr<const float>(beta),
-                       eps, momentum, ptr<float>(rm), ptr<float>(rv), ptr<long>(nbt), ptr<float>(mean),
-                       ptr<float>(invstd), ptr<float>(scale), ptr<float>(shift), st(s));
+  m.def("bn_stats_floats", [](long nparts, long C) { return bn_stats_floats(nparts, C); });
+  m.def("bn_fold_moments", [](uintptr_t partial, int nparts, int C, uintptr_t tmp, uintptr_t counter, double count,
+                              uintptr_t mean, uintptr_t m2, uintptr_t count_out, uintptr_t s) {
+    bn_fold_moments_launch(ptr<const float>(partial), nparts, C, ptr<double>(tmp), ptr<int>(counter), count,
+                           ptr<float>(mean), ptr<float>(m2), ptr<float>(count_out), st(s));
+  });
+  m.def("bn_sync_merge", [](uintptr_t gathered, int W, int C, uintptr_t gamma, uintptr_t beta, float eps, float momentum,
+                            uintptr_t rm, uintptr_t rv, uintptr_t nbt, uintptr_t mean, uintptr_t invstd, uintptr_t scale,
+                            uintptr_t shift, uintptr_t count_out, uintptr_t s) {
+    bn_sync_merge_launch(ptr<const float>(gathered), W, C, ptr<const float>(gamma), ptr<const float>(beta), eps, momentum,
+                         ptr<float>(rm), ptr<float>(rv), ptr<long>(nbt), ptr<float>(mean), ptr<float>(invstd),
+                         ptr<float>(scale), ptr<float>(shift), ptr<float>(count_out), st(s));
   });
   m.def("bn_eval_coeffs", [](uintptr_t gamma, uintptr_t beta, uintptr_t rm, uintptr_t rv, float eps, int C,
                              uintptr_t scale, uintptr_t shift, uintptr_t s) {

@@ -74,11 +74,22 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   }
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min(M, r_begin + rows_per_block);
+  // MODE 0 leaves (sum, M2 about the block mean, rows) -- Chan's partials -- not a raw sum of squares (which cancels
+  // catastrophically in fp32 when |mean| >> std): sums of (v - k), (v - k)^2 with k = the block's first row.
+  float ksh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) ksh[j] = 0.f;
+  if (MODE == 0 && active && r_begin < r_end) {
+    Vec16<T> k0;
+    k0.load(a + (size_t)r_begin * C + c0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ksh[j] = k0.get(j);
+  }
   auto accumulate = [&](const Vec16<T>& va, const Vec16<T>& vx, const Vec16<T>& vy, uint32_t bits) {
     if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const float f = va.get(j);
+        const float f = va.get(j) - ksh[j];
         s1[j] += f;
         s2[j] += f * f;
       }
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
     red[1][tid * VEC + j] = s2[j];
   }
   __syncthreads();
+  const float nb = r_end > r_begin ? (float)(r_end - r_begin) : 0.f;
   // thread t < ccb*VEC sums channel (t) over row lanes
   for (int t = tid; t < ccb * VEC; t += kBnThreads) {
     const int cchunk = t / VEC, j = t - cchunk * VEC;
@@ -148,28 +160,46 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       a2 += red[1][(q * ccb + cchunk) * VEC + j];
     }
     const int c = cc0 * VEC + t;
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a1;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = a2;
+    if (MODE == 0) {
+      const float k = nb > 0.f ? to_float(a[(size_t)r_begin * C + c]) : 0.f;
+      partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a1 + nb * k;
+      partial[((size_t)blockIdx.x * 2 + 1) * C + c] = nb > 0.f ? fmaxf(a2 - a1 * a1 / nb, 0.f) : 0.f;
+    } else {
+      partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a1;
+      partial[((size_t)blockIdx.x * 2 + 1) * C + c] = a2;
+    }
   }
+  // rows of this part, behind the slab ([gridDim.x][2][C] floats, then [gridDim.x] counts)
+  if (MODE == 0 && tid == 0 && blockIdx.y == 0) partial[(size_t)gridDim.x * 2 * C + blockIdx.x] = nb;
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts, int C, double count,
-                                   const float* __restrict__ count_dev, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var,
-                                   long* num_batches_tracked, float* mean, float* invstd, float* scale,
-                                   float* shift) {
+// SyncBatchNorm: Chan / Welford parallel merge of the ranks' local moments (Apex `welford_parallel`, reference
+// imagenet_ddp_apex.py:146-148).  gathered: [W][2C + 1] = (mean_r[C], M2_r[C], n_r) per rank.
+//   n = sum n_r;  mean = sum n_r mean_r / n;  M2 = sum M2_r + sum n_r (mean_r - mean)^2
+// in double, with the deviations taken from the MERGED mean (no E[x^2] - mean^2 anywhere).
+__global__ void bn_sync_merge_kernel(const float* __restrict__ gathered, int W, int C,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     float momentum, float* running_mean, float* running_var,
+                                     long* num_batches_tracked, float* mean, float* invstd, float* scale,
+                                     float* shift, float* count_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   if (c >= C) return;
-  if (count_dev != nullptr) count = (double)count_dev[0];
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nparts; ++k) {
-    s1 += (double)partial[((size_t)k * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)k * 2 + 1) * C + c];
+  const int ld = 2 * C + 1;
+  double n = 0.0, sm = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const double nr = (double)gathered[(size_t)r * ld + 2 * C];
+    n += nr;
+    sm += nr * (double)gathered[(size_t)r * ld + c];
   }
-  const double m = s1 / count;
-  double var = s2 / count - m * m;
-  if (var < 0.0) var = 0.0;
+  const double m = n > 0.0 ? sm / n : 0.0;
+  double m2 = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const double nr = (double)gathered[(size_t)r * ld + 2 * C];
+    const double d = (double)gathered[(size_t)r * ld + c] - m;
+    m2 += (double)gathered[(size_t)r * ld + C + c] + nr * d * d;
+  }
+  const double var = n > 0.0 ? m2 / n : 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)m;
   invstd[c] = is;
@@ -177,10 +207,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts
   scale[c] = g * is;
   shift[c] = b - (float)m * g * is;
   if (running_mean != nullptr) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
+  if (c == 0 && count_out != nullptr) count_out[0] = (float)n;
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -282,6 +313,21 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
   const int g = blockIdx.x, j = blockIdx.y;
   const int c = g * 64 + cl, C = a.C;
   const int p0 = j * a.chunk, p1 = min(a.nparts, p0 + a.chunk);
+  // Forward statistics (MODE 0 / 2): part k holds (sum_k, M2_k about its own mean) and its row count n_k sits behind
+  // the slab.  The additive quantities of Chan's merge are  S = sum_k  and  Q = M2_k + sum_k^2 / n_k  (in double:
+  // M2_k is small and exact, the big term is formed in 53 bits), total M2 = Q - S^2 / n.
+  const float* __restrict__ cnt = a.partial + (size_t)a.nparts * 2 * C;
+  float inv_n_of = -1.f;       // the parts of a slab have the same row count except the last: one division, reused
+  double inv_n = 0.0;
+  auto second = [&](int k, float sum_k, float b_k) -> double {
+    if (MODE == 1) return (double)b_k;
+    const float nk = cnt[k];
+    if (nk != inv_n_of) {
+      inv_n_of = nk;
+      inv_n = nk > 0.f ? 1.0 / (double)nk : 0.0;
+    }
+    return (double)b_k + (double)sum_k * (double)sum_k * inv_n;
+  };
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int k = p0 + pl;
@@ -291,11 +337,12 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
       const float a2 = a.partial[((size_t)(k + 8) * 2 + 0) * C + c], b2 = a.partial[((size_t)(k + 8) * 2 + 1) * C + c];
       const float a3 = a.partial[((size_t)(k + 12) * 2 + 0) * C + c], b3 = a.partial[((size_t)(k + 12) * 2 + 1) * C + c];
       s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+      s2 += (second(k, a0, b0) + second(k + 4, a1, b1)) + (second(k + 8, a2, b2) + second(k + 12, a3, b3));
     }
     for (; k < p1; k += 4) {
-      s1 += (double)a.partial[((size_t)k * 2 + 0) * C + c];
-      s2 += (double)a.partial[((size_t)k * 2 + 1) * C + c];
+      const float a0 = a.partial[((size_t)k * 2 + 0) * C + c], b0 = a.partial[((size_t)k * 2 + 1) * C + c];
+      s1 += (double)a0;
+      s2 += second(k, a0, b0);
     }
   }
   red[0][pl][cl] = s1;
@@ -345,10 +392,16 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
   if (pl != 0 || c >= C) return;
   const double t1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
   const double t2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-  if (MODE == 0) {
+  if (MODE == 2) {           // local moments only (SyncBatchNorm: merged across ranks afterwards)
+    const double m = t1 / a.count;
+    double m2 = t2 - t1 * m;
+    a.mean[c] = (float)m;
+    a.invstd[c] = (float)(m2 > 0.0 ? m2 : 0.0);      // M2, not an inverse std
+    if (c == 0 && a.scale != nullptr) a.scale[0] = (float)a.count;
+  } else if (MODE == 0) {
     if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
     const double m = t1 / a.count;
-    double var = t2 / a.count - m * m;
+    double var = (t2 - t1 * m) / a.count;
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)a.eps));
     a.mean[c] = (float)m;
@@ -706,14 +759,12 @@ void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, 
   col_reduce<1>(dy, x, y, M, C, dtype, mean, invstd, relu | (nt ? 256 : 0), scale, shift, partial, nblk, s);
 }
 
-void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* count_dev,
-                        const float* gamma,
-                        const float* beta, float eps, float momentum, float* running_mean,
-                        float* running_var, long* num_batches_tracked, float* mean, float* invstd,
-                        float* scale, float* shift, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partial, nparts, C, count,
-                     count_dev, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd,
-                     scale, shift);
+void bn_sync_merge_launch(const float* gathered, int W, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
+                          float* mean, float* invstd, float* scale, float* shift, float* count_out, hipStream_t s) {
+  if (W <= 0 || C <= 0) return;
+  hipLaunchKernelGGL(bn_sync_merge_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, gathered, W, C, gamma, beta, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift, count_out);
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -821,6 +872,7 @@ static void fold_finalize_launch(int mode, BnFinalizeArgs a, hipStream_t s) {
   if (ceil_div(a.C, 64) > 256) throw std::invalid_argument("bn_fold_finalize: more than 16384 channels");
   dim3 grid(ceil_div(a.C, 64), a.nchunk);
   if (mode == 0) hipLaunchKernelGGL(bn_fold_finalize_kernel<0>, grid, dim3(256), 0, s, a);
+  else if (mode == 2) hipLaunchKernelGGL(bn_fold_finalize_kernel<2>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(bn_fold_finalize_kernel<1>, grid, dim3(256), 0, s, a);
   DPA_CHECK_HIP(hipGetLastError());
 }
@@ -835,6 +887,14 @@ void bn_fold_finalize_launch(const float* partial, int nparts, int C, double* tm
   a.running_var = running_var; a.num_batches_tracked = num_batches_tracked;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift;
   fold_finalize_launch(0, a, s);
+}
+
+void bn_fold_moments_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
+                            float* mean, float* m2, float* count_out, hipStream_t s) {
+  BnFinalizeArgs a{};
+  a.partial = partial; a.nparts = nparts; a.C = C; a.tmp = tmp; a.counter = counter; a.count = count;
+  a.mean = mean; a.invstd = m2; a.scale = count_out;
+  fold_finalize_launch(2, a, s);
 }
 
 void bn_bwd_fold_finalize_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,

@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
   const int PH = BWD ? g.IH : g.OH, PW = BWD ? g.IW : g.OW;     // extents of the tensor being written
   const int SH = BWD ? g.OH : g.IH, SW = BWD ? g.OW : g.IW;     // extents of the tensor being read
   const uint32_t npix = (uint32_t)g.NB * PH * PW;              // < 2^31, checked by the launcher
-  float s1[VEC], s2[VEC];
+  // statistics: per thread sums of (v - k), (v - k)^2 with k = the thread's first output (see bn.hip: the slab holds
+  // Chan partials (sum, M2, rows), never a raw sum of squares)
+  float s1[VEC], s2[VEC], kk[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+  for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = kk[j] = 0.f;
+  float npx = 0.f;
   const bool active = ch < chunks;
   const int st_y = g.sh, st_x = g.sw;
   for (uint32_t pix = blockIdx.x * PXL + pl; pix < npix; pix += gridDim.x * PXL) {
@@ -142,30 +145,43 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
       o.set(j, v);
       if (!BWD && stats != nullptr) {
         const float rv = o.get(j);           // what BatchNorm will read back
-        s1[j] += rv;
-        s2[j] += rv * rv;
+        if (npx == 0.f) kk[j] = rv;
+        const float f = rv - kk[j];
+        s1[j] += f;
+        s2[j] += f * f;
       }
     }
+    npx += 1.f;
     o.store(out + (long)pix * g.C + ch * VEC);
   }
   if (!BWD && stats != nullptr) {
+    // per thread (sum, M2 about the thread's mean, pixels); the pixel lanes are merged in double (Chan)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      red[0][threadIdx.x][j] = s1[j];
-      red[1][threadIdx.x][j] = s2[j];
+      red[0][threadIdx.x][j] = s1[j] + npx * kk[j];
+      red[1][threadIdx.x][j] = npx > 0.f ? fmaxf(s2[j] - s1[j] * s1[j] / npx, 0.f) : 0.f;
     }
+    red[0][threadIdx.x][VEC] = npx;
     __syncthreads();
     if (pl == 0 && active) {
+      double N = 0.0;
+      for (int p = 0; p < PXL; ++p) N += (double)red[0][p * CSL + cl][VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        float a = 0.f, b = 0.f;
+        double S = 0.0, Q = 0.0;
         for (int p = 0; p < PXL; ++p) {
-          a += red[0][p * CSL + cl][j];
-          b += red[1][p * CSL + cl][j];
+          const double n = (double)red[0][p * CSL + cl][VEC];
+          if (n > 0.0) {
+            const double a = (double)red[0][p * CSL + cl][j];
+            S += a;
+            Q += (double)red[1][p * CSL + cl][j] + a * a / n;
+          }
         }
-        stats[((size_t)blockIdx.x * 2 + 0) * g.C + ch * VEC + j] = a;
-        stats[((size_t)blockIdx.x * 2 + 1) * g.C + ch * VEC + j] = b;
+        const double m2 = N > 0.0 ? Q - S * S / N : 0.0;
+        stats[((size_t)blockIdx.x * 2 + 0) * g.C + ch * VEC + j] = (float)S;
+        stats[((size_t)blockIdx.x * 2 + 1) * g.C + ch * VEC + j] = (float)(m2 > 0.0 ? m2 : 0.0);
       }
+      if (blockIdx.y == 0 && cl == 0) stats[(size_t)gridDim.x * 2 * g.C + blockIdx.x] = (float)N;
     }
   }
 }

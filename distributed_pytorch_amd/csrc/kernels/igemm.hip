@@ -147,6 +147,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   float s1[VECO], s2[VECO];
 #pragma unroll
   for (int j = 0; j < VECO; ++j) s1[j] = s2[j] = 0.f;
+  // BatchNorm statistics of this tile leave as (sum, M2 = sum of squared deviations from the TILE mean) -- the
+  // partials of Chan's parallel variance -- never as a raw sum of squares, which cancels catastrophically in fp32
+  // when |mean| >> std.  They are accumulated as sums of (v - k) and (v - k)^2 with k = the tile's first row (a
+  // sample, so |v - k| ~ std) and converted when the tile's waves meet.
+  float kshift[VECO];
+#pragma unroll
+  for (int j = 0; j < VECO; ++j) kshift[j] = 0.f;
+  if constexpr (!BNB) {
+    if (p.stats != nullptr) {
+      Vec16<TOut> k0;
+      k0.load(se + ce * 16);
+#pragma unroll
+      for (int j = 0; j < VECO; ++j) kshift[j] = k0.get(j);
+    }
+  }
   char* __restrict__ Cg = reinterpret_cast<char*>(p.C) + gofs * sizeof(TOut);
   // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column, and ALL
   // rows of the extra operands requested at once (inside the store loop each row paid a full memory latency;
@@ -237,7 +252,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     } else if (p.stats != nullptr) {
 #pragma unroll
       for (int j = 0; j < VECO; ++j) {
-        const float f = v.get(j);
+        const float f = v.get(j) - kshift[j];
         s1[j] += f;
         s2[j] += f * f;
       }
@@ -257,23 +272,42 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // epilogue tile fully consumed
     asm volatile("" ::: "memory");
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN]
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN] + shifts [BN]
     if (lane < CE) {
 #pragma unroll
       for (int j = 0; j < VECO; ++j) {
         red[(wave * 2 + 0) * BN + ce * VECO + j] = s1[j];
         red[(wave * 2 + 1) * BN + ce * VECO + j] = s2[j];
+        if (!BNB && wave == 0) red[8 * BN + ce * VECO + j] = kshift[j];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int c = tid; c < 2 * BN; c += 256) {
-      const int which = c / BN, col = c - which * BN;
-      if (n0 + col < p.N) {
-        const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
-                        red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
-        p.stats[((size_t)mt * 2 + which) * p.stats_ld + gofs + n0 + col] = s;
+    if constexpr (BNB) {
+      for (int c = tid; c < 2 * BN; c += 256) {
+        const int which = c / BN, col = c - which * BN;
+        if (n0 + col < p.N) {
+          const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
+                          red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
+          p.stats[((size_t)mt * 2 + which) * p.stats_ld + gofs + n0 + col] = s;
+        }
+      }
+    } else {
+      const float nt_rows = (float)min(BM, p.M - m0);
+      for (int col = tid; col < BN; col += 256) {
+        if (n0 + col < p.N) {
+          const float a = red[0 * BN + col] + red[2 * BN + col] + red[4 * BN + col] + red[6 * BN + col];
+          const float b = red[1 * BN + col] + red[3 * BN + col] + red[5 * BN + col] + red[7 * BN + col];
+          const float k = red[8 * BN + col];
+          p.stats[((size_t)mt * 2 + 0) * p.stats_ld + gofs + n0 + col] = a + nt_rows * k;
+          p.stats[((size_t)mt * 2 + 1) * p.stats_ld + gofs + n0 + col] = fmaxf(b - a * a / nt_rows, 0.f);
+        }
+      }
+      // rows of this part, behind the slab: [tiles_m][2][stats_ld] floats, then [tiles_m] counts
+      if (tid == 0 && n0 == 0 && blockIdx.y == 0) {
+        const uint32_t tiles_m = gridDim.x / ((p.N + BN - 1) / BN);
+        p.stats[(size_t)tiles_m * 2 * p.stats_ld + mt] = nt_rows;
       }
     }
   }
@@ -684,7 +718,7 @@ void launch_row3(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + 2 + 3 * BN) * LDR;
   constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
-  constexpr int red_bytes = 4 * 2 * BN * 4;
+  constexpr int red_bytes = 9 * BN * 4;
   constexpr int lds0 = stage_bytes > epi_bytes ? (stage_bytes > red_bytes ? stage_bytes : red_bytes)
                                                : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
   int lds = lds0;
@@ -916,7 +950,7 @@ template <typename T, typename TOut, int BM, int BN, int BKB, int S, int MINB>
 void launch_glds(const IgemmParams& p, hipStream_t stream) {
   constexpr int ring_bytes = S * (BM + BN) * BKB;
   constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
-  constexpr int red_bytes = 4 * 2 * BN * 4;
+  constexpr int red_bytes = 9 * BN * 4;
   constexpr int lds = ring_bytes > epi_bytes ? (ring_bytes > red_bytes ? ring_bytes : red_bytes)
                                              : (epi_bytes > red_bytes ? epi_bytes : red_bytes);
   auto kern = igemm_glds_kernel<T, TOut, BM, BN, BKB, S, MINB>;
@@ -935,7 +969,7 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + BN) * LDR;
   constexpr int epi_bytes = BM * (BN * (int)sizeof(TOut) + 16);
-  constexpr int red_bytes = 4 * 2 * BN * 4;
+  constexpr int red_bytes = 9 * BN * 4;
   constexpr int axf_bytes = AXF ? 8 * kAxfMaxCred : 0;
   constexpr int max_lds = 2 * stage_bytes + axf_bytes > epi_bytes ? 2 * stage_bytes + axf_bytes : epi_bytes;
   // a single K tile (1x1 convolutions with few input channels) needs no second staging buffer

@@ -98,12 +98,17 @@ int bn_partial_rows(long M, int C);
 // folds [nparts][2][C] partials into [nout][2][C] (nout*ceil(nparts/nout) >= nparts; empty parts give 0)
 void bn_fold_partials_launch(const float* partial, int nparts, int C, float* out, int nout, hipStream_t s);
 void bn_stats_launch(const void* x, long M, int C, int dtype, float* partial, int nblk, hipStream_t s);
-// partial: [nparts][2][C] (sum, sumsq) over `count` rows total -> mean, invstd, scale/shift, running update
-void bn_finalize_launch(const float* partial, int nparts, int C, double count, const float* count_dev,
-                        const float* gamma,
-                        const float* beta, float eps, float momentum, float* running_mean,
-                        float* running_var, long* num_batches_tracked, float* mean, float* invstd,
-                        float* scale, float* shift, hipStream_t s);
+// Forward statistics slabs ("stats"): [nparts][2][C] floats = (sum, M2 about the part's own mean) per part, followed by
+// [nparts] floats = rows of each part (bn_stats_floats()).  These are the partials of Chan's parallel variance; no
+// kernel forms E[x^2] - mean^2 in fp32.  Producers: bn_stats_launch, the igemm epilogue (IgemmParams::stats), dw_conv.
+inline long bn_stats_floats(long nparts, long C) { return nparts * 2 * C + nparts; }
+// local moments of one rank (SyncBatchNorm): mean[C], M2[C] about that mean, count_out[0] = count
+void bn_fold_moments_launch(const float* partial, int nparts, int C, double* tmp, int* counter, double count,
+                            float* mean, float* m2, float* count_out, hipStream_t s);
+// gathered: [W][2C + 1] = (mean_r, M2_r, n_r) of every rank -> Chan merge -> mean, invstd, scale/shift, running update
+void bn_sync_merge_launch(const float* gathered, int W, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, long* num_batches_tracked,
+                          float* mean, float* invstd, float* scale, float* shift, float* count_out, hipStream_t s);
 void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, int C, float* scale, float* shift,
                            hipStream_t s);

@@ -13,6 +13,7 @@ reference's ``model(images)``, ``criterion``, ``loss.backward()`` and
 from __future__ import annotations
 
 import math
+import functools
 import os
 from typing import Dict, Optional, Tuple
 
@@ -257,11 +258,18 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
               a_scale, a_shift)
 
 
+def _stats_slab(nparts: int, C_: int, device) -> torch.Tensor:
+    """Forward-statistics slab [nparts][2][C] = Chan partials (sum, M2 about the part's mean) with the parts' row
+    counts stored right behind it (``kernels.h: bn_stats_floats``).  The view keeps the tail alive."""
+    flat = torch.empty(nparts * 2 * C_ + nparts, dtype=torch.float32, device=device)
+    return flat[:nparts * 2 * C_].view(nparts, 2, C_)
+
+
 def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
     """fp32 column sums of [M, C] (bias gradients) through the BN column reducer."""
     M, Cc = dy2d.shape
     nblk = C().bn_partial_rows(M, Cc)
-    part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dy2d.device)
+    part = _stats_slab(nblk, Cc, dy2d.device)
     C().bn_stats(dy2d.data_ptr(), M, Cc, _dt(dy2d), part.data_ptr(), nblk, _stream())
     s1 = torch.empty(Cc, dtype=torch.float32, device=dy2d.device)
     s2 = torch.empty(Cc, dtype=torch.float32, device=dy2d.device)
@@ -313,7 +321,7 @@ class _ConvFn(torch.autograd.Function):
         stats = None
         if want_stats:
             tiles = C().igemm_stats_rows(M, K, Cx, R * S, _dt(x), _dt(x))
-            stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+            stats = _stats_slab(tiles, K, x.device)
         taps = _tap_table(x.device, _fprop_taps(R, S, ph, pw))
         bias_f = None
         if bias is not None:
@@ -435,6 +443,29 @@ _pending_bnred: Dict[int, tuple] = {}
 # inside the data-gradient epilogue): saves writing the masked copy (one activation-sized tensor per block).
 _pending_mask: Dict[int, tuple] = {}
 _LAZY_DRES = os.environ.get("DPA_LAZY_DRES", "1") == "1"
+
+
+class _LazyTok:
+    """One per residual BatchNorm + ReLU call that may hand back an UNMASKED residual gradient.  A tensor hook on the
+    residual sees the gradient autograd is about to deliver to the residual's producer: when the residual had a
+    second consumer that is a SUM of several gradients (a new tensor, or an in-place accumulation), the pending
+    mask can no longer be applied by the producer, so the hook repairs the sum here (cold path)."""
+    __slots__ = ("ent",)
+
+    def __init__(self):
+        self.ent = None         # (dy as handed back, bit mask, dy._version)
+
+
+def _lazy_res_hook(tok: "_LazyTok", grad: torch.Tensor):
+    ent, tok.ent = tok.ent, None
+    if ent is None:
+        return None
+    dy, mask, ver = ent
+    if grad.data_ptr() == dy.data_ptr() and grad._version == ver and grad.shape == dy.shape:
+        return None             # the only consumer: the producer pops _pending_mask and masks in its own kernel
+    _pending_mask.pop(dy.data_ptr(), None)
+    # grad = (unmasked dy) + others  ->  (masked dy) + others
+    return grad - (dy - apply_bit_mask(dy, mask))
 
 
 bn_bwd_counts = {"fused": 0, "reduced": 0}      # how BatchNorm backward obtained its partial sums (tests, tuning)
@@ -693,7 +724,7 @@ class _GroupConvFn(torch.autograd.Function):
         stats = None
         if want_stats:
             tiles = C().igemm_stats_rows(M, Kout, Cin, R * S, _dt(x), _dt(x))
-            stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+            stats = _stats_slab(tiles, K, x.device)
         taps = _tap_table(x.device, _fprop_taps(R, S, ph, pw))
         bias_f = None
         if bias is not None:
@@ -797,7 +828,7 @@ class _DepthwiseConvFn(torch.autograd.Function):
         y = torch.empty((NB, OH, OW, K), dtype=x.dtype, device=x.device)
         stats = None
         if want_stats:
-            stats = torch.empty((C().dw_conv_rows(NB * OH * OW, K, _dt(x)), 2, K), dtype=torch.float32, device=x.device)
+            stats = _stats_slab(C().dw_conv_rows(NB * OH * OW, K, _dt(x)), K, x.device)
         bias_f = None if bias is None else _f32(bias.detach()).contiguous()
         C().dw_conv(x.data_ptr(), w.data_ptr(), _dt(w), _p(bias_f), y.data_ptr(), _p(stats), 0, NB, IH, IW, K, OH, OW,
                     R, S, sh, sw, ph, pw, 1 if relu else 0, _dt(x), _stream())
@@ -910,6 +941,16 @@ def _group_size(group) -> int:
     return pg.get_world_size(None if group == "world" else group)
 
 
+def _gather_world(group):
+    """(ranks, this rank) of the group the statistics are merged over (1, 0 without a process group)."""
+    from ..parallel import process_group as pg
+
+    if group is None or not pg.is_initialized():
+        return 1, 0
+    g = None if group == "world" else group
+    return pg.get_world_size(g), pg.get_rank(g)
+
+
 def _all_reduce_sum(t: torch.Tensor, group) -> None:
     from ..parallel import process_group as pg
 
@@ -920,8 +961,9 @@ def _all_reduce_sum(t: torch.Tensor, group) -> None:
 class _BNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, momentum, eps, relu, stats,
-                group, defer=False):
+                group, defer=False, lazy_tok=None):
         x = x if x.is_contiguous() else x.contiguous()
+        ctx.lazy_tok = lazy_tok
         Cc = x.shape[-1]
         M = x.numel() // Cc
         st = _stream()
@@ -935,7 +977,7 @@ class _BNFn(torch.autograd.Function):
                 raise ValueError("batch_norm: a smooth activation cannot be combined with a residual")
         if stats is None:
             nblk = C().bn_partial_rows(M, Cc)
-            stats = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
+            stats = _stats_slab(nblk, Cc, dev)
             C().bn_stats(x.data_ptr(), M, Cc, _dt(x), stats.data_ptr(), nblk, st)
         count = float(M)
         count_dev = None
@@ -943,18 +985,20 @@ class _BNFn(torch.autograd.Function):
         g32, b32 = _f32(weight.detach()), _f32(bias.detach())
         coef = torch.empty((4, Cc), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
         if world > 1:
-            part = _fold(stats, Cc)
-            # SyncBN: all-reduce [sum(C), sumsq(C), rows] -- one small message per layer
-            packed = torch.empty(2 * Cc + 1, dtype=torch.float32, device=dev)
-            C().bn_bwd_finalize(part.data_ptr(), part.shape[0], Cc, packed[Cc:2 * Cc].data_ptr(),
-                                packed[:Cc].data_ptr(), st)
-            packed[2 * Cc:].fill_(float(M))
-            _all_reduce_sum(packed, group)
-            count_dev = packed[2 * Cc:]
-            part = packed[:2 * Cc].view(1, 2, Cc)
-            C().bn_finalize(part.data_ptr(), part.shape[0], Cc, count, _p(count_dev), g32.data_ptr(),
-                            b32.data_ptr(), eps, momentum, _p(running_mean), _p(running_var), _p(nbt),
-                            coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), st)
+            # SyncBN: local moments (mean, M2, n) -> all ranks -> Chan / Welford merge (Apex `welford_parallel`,
+            # imagenet_ddp_apex.py:146-148).  The gather is an all-reduce of a zeroed [W][2C + 1] table in which
+            # every rank fills its own row (x + 0 is exact), so it rides the small-message peer path.
+            W, r = _gather_world(group)
+            table = torch.zeros((W, 2 * Cc + 1), dtype=torch.float32, device=dev)
+            row = table[r]
+            tmp, tickets = _bn_scratch(stats.shape[0], Cc, dev)
+            C().bn_fold_moments(stats.data_ptr(), stats.shape[0], Cc, _p(tmp), tickets.data_ptr(), count,
+                                row[:Cc].data_ptr(), row[Cc:2 * Cc].data_ptr(), row[2 * Cc:].data_ptr(), st)
+            _all_reduce_sum(table, group)
+            count_dev = torch.empty(1, dtype=torch.float32, device=dev)
+            C().bn_sync_merge(table.data_ptr(), W, Cc, g32.data_ptr(), b32.data_ptr(), eps, momentum,
+                              _p(running_mean), _p(running_var), _p(nbt), coef[0].data_ptr(), coef[1].data_ptr(),
+                              coef[2].data_ptr(), coef[3].data_ptr(), count_dev.data_ptr(), st)
         else:
             # one launch folds the per-tile partial slab and writes mean / invstd / scale / shift + running stats
             tmp, tickets = _bn_scratch(stats.shape[0], Cc, dev)
@@ -1012,7 +1056,8 @@ class _BNFn(torch.autograd.Function):
         # convolution only, so backward may return dy itself + the bit mask instead of a masked copy
         # ... or the output of an activation-free BatchNorm (the downsample branch), whose backward takes the bit
         # mask as its own "ReLU" mask
-        ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and residual.shape == x.shape and residual.dtype == x.dtype
+        ctx.lazy_res = bool(relu_mode == 3 and _LAZY_DRES and lazy_tok is not None
+                            and residual.shape == x.shape and residual.dtype == x.dtype
                             and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)))
         ctx.cfg = (relu_mode | clip | (act << 4), residual is not None, group, count)
         _BNFn.last = None if (clip or act) else _BnSrc(x, coef, relu_mode, mask)
@@ -1083,6 +1128,7 @@ class _BNFn(torch.autograd.Function):
                          wk.data_ptr(), relu, st)
         if lazy:                 # y is the bit mask here (relu mode 3); the consumer applies it in its dgrad epilogue
             _pending_mask[dy.data_ptr()] = (y, dy._version, _generation)
+            ctx.lazy_tok.ent = (dy, y, dy._version)       # holding dy also keeps autograd from accumulating into it
             dres = dy
         if direct:
             sw_.delivered()
@@ -1091,7 +1137,7 @@ class _BNFn(torch.autograd.Function):
         else:
             dgamma = _deliver(weight, dg_t.to(weight.dtype)) if ctx.needs_input_grad[1] else None
             dbeta = _deliver(bias_p, db_t.to(bias_p.dtype)) if ctx.needs_input_grad[2] else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 _FUSE_STEM = os.environ.get("DPA_FUSE_STEM", "1") == "1"
@@ -1123,7 +1169,7 @@ class _BNReluMaxPoolFn(torch.autograd.Function):
         dev = x.device
         if stats is None:
             nblk = C().bn_partial_rows(M, Cc)
-            stats = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dev)
+            stats = _stats_slab(nblk, Cc, dev)
             C().bn_stats(x.data_ptr(), M, Cc, _dt(x), stats.data_ptr(), nblk, st)
         g32, b32 = _f32(weight.detach()), _f32(bias.detach())
         coef = torch.empty((4, Cc), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
@@ -1252,11 +1298,18 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
         grad_sink.note_use(weight, bias)
         _BNFn.last = None
         _BNFn.deferred = None
+        tok = None
+        if _LAZY_DRES and residual is not None and residual.requires_grad and torch.is_grad_enabled() \
+                and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)):
+            # the lazy residual gradient is only right when this BN is the residual's sole consumer; nothing in the
+            # forward pass can know that, so a hook on the residual checks what autograd finally delivers
+            tok = _LazyTok()
+            residual.register_hook(functools.partial(_lazy_res_hook, tok))
         y = _BNFn.apply(x, weight, bias, residual, running_mean if training else None,
                         running_var if training else None, num_batches_tracked if training else None,
                         float(momentum if momentum is not None else 0.1), float(eps), _act_code(relu), stats, group,
                         bool(defer and training and torch.is_grad_enabled()
-                             and (_AXF if relu else _DEFER_BN)))
+                             and (_AXF if relu else _DEFER_BN)), tok)
         if _BNFn.deferred is not None:
             y._dpa_deferred_coef = _BNFn.deferred
             y._dpa_deferred_relu = _BNFn.deferred_relu
@@ -1980,7 +2033,7 @@ class _StemS2DFn(torch.autograd.Function):
         stats = None
         if want_stats:
             tiles = C().igemm_stats_rows(M, K, 16, 16, _dt(x), _dt(x))
-            stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+            stats = _stats_slab(tiles, K, x.device)
         taps = _tap_table(x.device, _S2D_TAPS)
         bias_f = None
         if bias is not None:

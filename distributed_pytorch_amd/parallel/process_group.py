@@ -259,10 +259,10 @@ def is_initialized() -> bool:
     return d.is_available() and d.is_initialized()
 
 
-def get_rank() -> int:
+def get_rank(group=None) -> int:
     if _NATIVE is not None:
         return _NATIVE.rank
-    return _tdist().get_rank() if is_initialized() else 0
+    return _tdist().get_rank(group) if is_initialized() else 0
 
 
 def get_world_size(group=None) -> int:

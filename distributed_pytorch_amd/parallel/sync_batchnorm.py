@@ -1,9 +1,11 @@
 """SyncBatchNorm: batch statistics over every rank of the process group.
 
 Replaces ``apex.parallel.convert_syncbn_model`` (reference
-``imagenet_ddp_apex.py:146-148``).  Forward: local per-channel ``[sum, sumsq, n]``
-(fp32) -> ONE all-reduce of a ``2C+1`` vector -> mean / biased var -> normalise;
-``running_var`` gets the unbiased global variance.  Backward: ONE all-reduce of
+``imagenet_ddp_apex.py:146-148``).  Forward: local per-channel moments ``[mean, M2, n]``
+(M2 = sum of squared deviations from the LOCAL mean, never a raw sum of squares) -> gathered
+from every rank (one small collective: an all-reduce of a zeroed ``[W, 2C+1]`` table in which
+each rank fills its row) -> Chan / Welford parallel merge, as Apex ``welford_parallel`` does
+-> normalise; ``running_var`` gets the unbiased global variance.  Backward: ONE all-reduce of
 ``[sum(dy), sum(dy*xhat)]`` (``2C`` floats), then the usual BN input gradient with
 the global element count (collective inventory C-h / C-i).
 
@@ -39,6 +41,17 @@ def all_reduce_sum_(t: torch.Tensor, group) -> torch.Tensor:
     return t
 
 
+def chan_merge(table: torch.Tensor, c: int):
+    """[W, 2C+1] rows (mean_r, M2_r, n_r) -> (mean, biased var, n):  n = sum n_r,  mean = sum n_r mean_r / n,
+    M2 = sum M2_r + sum n_r (mean_r - mean)^2  (Chan et al.; deviations from the MERGED mean, in double)."""
+    t = table.double()
+    n_r = t[:, 2 * c:2 * c + 1]
+    count = n_r.sum()
+    mean = (n_r * t[:, :c]).sum(0) / count
+    m2 = t[:, c:2 * c].sum(0) + (n_r * (t[:, :c] - mean).square()).sum(0)
+    return mean.float(), (m2 / count).float(), count.float()
+
+
 class _SyncBNFunction(torch.autograd.Function):
     """Reference (pure torch) SyncBN over NHWC input; used for CPU tensors."""
 
@@ -46,12 +59,15 @@ class _SyncBNFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, nbt, momentum, eps, group):
         c = x.shape[-1]
         xf = x.reshape(-1, c).float()
-        packed = torch.cat([xf.sum(0), (xf * xf).sum(0),
-                            torch.tensor([float(xf.shape[0])], device=x.device)])
-        all_reduce_sum_(packed, group)
-        count = packed[-1]
-        mean = packed[:c] / count
-        var = (packed[c:2 * c] / count - mean * mean).clamp_min_(0.0)
+        world = _world(group)
+        rank = pg.get_rank(_group(group)) if world > 1 else 0
+        lmean = xf.mean(0)
+        table = torch.zeros(world, 2 * c + 1, dtype=torch.float32, device=x.device)
+        table[rank, :c] = lmean
+        table[rank, c:2 * c] = (xf - lmean).square().sum(0)
+        table[rank, 2 * c] = float(xf.shape[0])
+        all_reduce_sum_(table, group)
+        mean, var, count = chan_merge(table, c)
         invstd = torch.rsqrt(var + eps)
         if running_mean is not None:
             with torch.no_grad():

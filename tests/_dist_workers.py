@@ -63,13 +63,15 @@ def ddp_grads(local_rank, world, port, out_dir, delay, backend="gloo"):
     _finish()
 
 
-def syncbn_stats(local_rank, world, port, out_dir, backend="gloo"):
+def syncbn_stats(local_rank, world, port, out_dir, backend="gloo", offset=0.0):
     from distributed_pytorch_amd.nn.modules import BatchNorm2d
     from distributed_pytorch_amd.parallel import convert_syncbn_model
 
     _init(local_rank, world, port, backend)
     torch.manual_seed(7)
-    x = torch.randn(8, 5, 5, 16)
+    x = torch.randn(8, 5, 5, 16) + offset          # offset = 1e3: |mean| = 1000 std (Welford / Chan territory)
+    if offset:
+        x[4:] += 0.5                                # the two ranks' local means differ: the merge term matters
     bn = convert_syncbn_model(torch.nn.Sequential(BatchNorm2d(16)))[0]
     per = 8 // world
     xs = x[local_rank * per:(local_rank + 1) * per].clone().requires_grad_(True)

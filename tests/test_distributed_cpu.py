@@ -189,6 +189,24 @@ def test_syncbn_equals_batchnorm_over_the_global_batch(tmp_path, backend):
     assert torch.allclose(rs[0]["dw"] + rs[1]["dw"], bn.weight.grad, atol=1e-4)     # local sums; DDP averages
 
 
+def test_syncbn_chan_merge_survives_mean_1000_std(tmp_path):
+    """Apex merges (mean, M2, n) partials (welford_parallel, imagenet_ddp_apex.py:146-148); E[x^2] - mean^2 in fp32 has
+    lost every digit of the variance at |mean| = 1e3 std.  Oracle: float64 statistics of the global batch."""
+    world = 2
+    launch.spawn(W.syncbn_stats, world, (world, _port(), str(tmp_path), "gloo", 1000.0))
+    rs = [torch.load(tmp_path / ("rank%d.pt" % r), weights_only=True) for r in range(world)]
+    torch.manual_seed(7)
+    x = torch.randn(8, 5, 5, 16) + 1000.0
+    x[4:] += 0.5
+    xd = x.double().reshape(-1, 16)
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    yref = ((xd - mean) / (var + 1e-5).sqrt()).reshape(x.shape)
+    y = torch.cat([r["y"] for r in rs]).double()
+    assert (y - yref).abs().max() < 2e-3, (y - yref).abs().max()          # fp32 input spacing at 1000 is 6e-5
+    assert torch.allclose(rs[0]["rv"].double(), 0.9 + 0.1 * xd.var(0, unbiased=True), rtol=1e-3)
+    assert torch.allclose(rs[0]["rm"].double(), 0.1 * mean, rtol=1e-6)
+
+
 def test_rank_failure_tears_the_job_down_instead_of_hanging():
     t0 = time.time()
     with pytest.raises(launch.ProcessFailure) as e:

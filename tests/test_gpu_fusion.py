@@ -102,3 +102,93 @@ def test_deferred_bn_relu_into_grouped_conv_materialises():
         outs.append((y.detach(), x.grad, w.grad))
     for u, v in zip(*outs):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("kind", ["plain_bn", "alias"])
+def test_lazy_residual_gradient_with_a_second_consumer(kind):
+    """The residual of a BN + add + ReLU normally gets its gradient back UNMASKED plus a bit mask that its producer
+    applies.  When the residual has a second consumer autograd sums the gradients first; the tensor hook must then
+    repair the sum (silent wrong gradients otherwise).  Reference: the same graph with the lazy path off."""
+    dtype = torch.bfloat16
+    torch.manual_seed(21)
+    x0 = torch.randn(2, 8, 8, 64, device=DEV).to(dtype)
+    wa0 = (torch.randn(64, 64, 1, 1, device=DEV) / 8).contiguous(memory_format=torch.channels_last)
+    wb0 = (torch.randn(64, 64, 3, 3, device=DEV) / 24).contiguous(memory_format=torch.channels_last)
+    ga, ba = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1
+    gb, bb = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1
+
+    def run(lazy):
+        old = hip_ops._LAZY_DRES
+        hip_ops._LAZY_DRES = lazy
+        try:
+            x = x0.clone().requires_grad_(True)
+            wa, wb = wa0.clone().requires_grad_(True), wb0.clone().requires_grad_(True)
+            if kind == "plain_bn":
+                res = F.batch_norm(F.conv2d(x, wa, None, 1, 0), ga, ba, None, None, None, True, 0.1, 1e-5)
+                main_in = x
+            else:
+                main_in, res = F.conv2d(x, wa, None, 1, 0, skip=True)      # res aliases x
+            y = F.batch_norm(F.conv2d(main_in, wb, None, 1, 1), gb, bb, None, None, None, True, 0.1, 1e-5,
+                             relu=True, residual=res)
+            second = (res.float() * 0.5).sum()                              # a consumer the framework knows nothing about
+            (y.float().square().sum() + second).backward()
+            return x.grad.float(), wa.grad.float(), wb.grad.float()
+        finally:
+            hip_ops._LAZY_DRES = old
+
+    lazy, ref = run(True), run(False)
+    for a, b, what in zip(lazy, ref, ("dx", "dwa", "dwb")):
+        assert_close(a, b, dtype, what="%s %s" % (kind, what))
+    assert len(hip_ops._pending_mask) == 0, "an unapplied ReLU mask was left behind"
+
+
+# ---- statistics at |mean| >> std (fp32): Chan partials instead of sums of squares ---------------------------------
+def _ref_stats(x2d):
+    xd = x2d.double()
+    return xd.mean(0), xd.var(0, unbiased=False)
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_batch_norm_statistics_at_mean_1000_std(sync):
+    """fp32 BatchNorm (and the SyncBN code path: local moments -> gather -> Chan merge) with mean = 1e3 std."""
+    torch.manual_seed(31)
+    C, M = 64, 4 * 33 * 29
+    x = (torch.randn(4, 33, 29, C, device=DEV) + 1000.0).requires_grad_(True)
+    g, b = torch.ones(C, device=DEV, requires_grad=True), torch.zeros(C, device=DEV, requires_grad=True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    old = hip_ops._FORCE_SYNC_PATH
+    hip_ops._FORCE_SYNC_PATH = sync
+    try:
+        y = F.batch_norm(x, g, b, rm, rv, None, True, 0.1, 1e-5, group="world" if sync else None)
+    finally:
+        hip_ops._FORCE_SYNC_PATH = old
+    mean, var = _ref_stats(x.detach().reshape(-1, C))
+    yref = ((x.detach().double() - mean) / (var + 1e-5).sqrt())
+    assert (y.double() - yref).abs().max().item() < 2e-3
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * var * M / (M - 1), rtol=1e-3), (rv.double() - (0.9 + 0.1 * var)).abs().max()
+    assert torch.allclose(rm.double(), 0.1 * mean, rtol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["dense", "depthwise"])
+def test_conv_epilogue_statistics_at_mean_1000_std(kind):
+    """The (sum, M2, rows) partials a convolution epilogue emits give the right variance when the conv output sits at
+    1e3 std from zero (bias = 1000): fp32, compared with float64 statistics of the kernel's own output."""
+    torch.manual_seed(32)
+    Cin = Cout = 64
+    x = torch.randn(3, 19, 17, Cin, device=DEV)
+    if kind == "dense":
+        w = (torch.randn(Cout, Cin, 3, 3, device=DEV) / 24).contiguous(memory_format=torch.channels_last)
+        groups = 1
+    else:
+        w = torch.randn(Cout, 1, 3, 3, device=DEV) / 3
+        groups = Cout
+    bias = torch.full((Cout,), 1000.0, device=DEV)
+    y, stats = F.conv2d(x, w, bias, 1, 1, want_stats=True, groups=groups)
+    C = Cout
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    out = F.batch_norm(y, torch.ones(C, device=DEV), torch.zeros(C, device=DEV), rm, rv, None, True, 0.1, 1e-5,
+                       stats=stats)
+    mean, var = _ref_stats(y.reshape(-1, C))
+    yref = (y.double() - mean) / (var + 1e-5).sqrt()
+    assert (out.double() - yref).abs().max().item() < 2e-3
+    assert torch.allclose(rm.double(), 0.1 * mean, rtol=1e-6)

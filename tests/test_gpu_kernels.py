@@ -23,6 +23,15 @@ def _close(a, b, dtype, scale=1.0, what=""):
     assert err <= atol * scale * max(ref, 1.0) + rtol * ref * 0, "%s: max err %g vs ref max %g" % (what, err, ref)
 
 
+def _slab_m2(stats):
+    """Total sum of squared deviations from a forward-statistics slab: rows (sum_t, M2_t) + the parts' row counts
+    stored behind the slab, merged with Chan's formula in float64."""
+    tiles = stats.shape[0]
+    cnt = stats.flatten().as_strided((tiles,), (1,), stats.numel()).double()
+    s, m2 = stats[:, 0].double(), stats[:, 1].double()
+    return (m2.sum(0) + (s * s / cnt[:, None]).sum(0) - s.sum(0) ** 2 / cnt.sum()).float()
+
+
 CONV_CASES = [
     # N, H, W, Cin, Cout, k, stride, pad
     (4, 14, 14, 64, 64, 1, 1, 0),
@@ -125,10 +134,16 @@ def test_conv_stats_epilogue(dtype):
     x = torch.randn(6, 14, 14, 64, device=DEV).to(dtype)
     w = (torch.randn(128, 64, 3, 3, device=DEV) / 24).contiguous(memory_format=torch.channels_last)
     y, stats = F.conv2d(x, w, None, 1, 1, want_stats=True)
-    s = stats.sum(0)
+    # per tile of 128 rows: (sum, M2 about the tile mean); the rows of each tile sit behind the slab
     yf = y.float().reshape(-1, 128)
-    _close(s[0], yf.sum(0), torch.float32, scale=10, what="sum")
-    _close(s[1], (yf * yf).sum(0), torch.float32, scale=10, what="sumsq")
+    tiles = stats.shape[0]
+    counts = stats.flatten().as_strided((tiles,), (1,), stats.numel())
+    assert counts.sum().item() == yf.shape[0]
+    _close(stats[:, 0].sum(0), yf.sum(0), torch.float32, scale=10, what="sum")
+    for t in (0, tiles - 1):
+        rows = yf[t * 128:(t + 1) * 128]
+        assert counts[t].item() == rows.shape[0]
+        _close(stats[t, 1], (rows - rows.mean(0)).square().sum(0), torch.float32, scale=10, what="M2 tile %d" % t)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -594,7 +609,7 @@ def test_group_conv_fwd_bwd(case, dtype, bias_relu):
     _close(y.permute(0, 3, 1, 2), yr, dtype, what="fprop")
     yf = y.detach().float().reshape(-1, Cout)
     _close(stats.sum(0)[0], yf.sum(0), torch.float32, scale=10, what="stats sum")
-    _close(stats.sum(0)[1], (yf * yf).sum(0), torch.float32, scale=10, what="stats sumsq")
+    _close(_slab_m2(stats), (yf - yf.mean(0)).square().sum(0), torch.float32, scale=10, what="stats M2")
     _close(xq.grad.permute(0, 3, 1, 2), xr.grad, dtype, what="dgrad")
     _close(w.grad, wr.grad, dtype, what="wgrad")
     if b is not None:
@@ -616,7 +631,7 @@ def test_depthwise_direct_equals_block_diagonal_path():
             x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
             y, stats = F.conv2d(x, w, None, 2, 1, groups=96, want_stats=True)
             y.backward(gy)
-            res.append((y.detach(), stats.sum(0), x.grad, w.grad))
+            res.append((y.detach(), torch.stack([stats[:, 0].sum(0), _slab_m2(stats)]), x.grad, w.grad))
     finally:
         hip_ops._DW_DIRECT = True
     for a, b in zip(*res):
