@@ -342,7 +342,12 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   const int mt = lid / tiles_n, nt = lid - mt * tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T);
+  // The gather base is the first image this tile touches: the 32-bit byte offsets of the aligned path then only have
+  // to span the few images of ONE tile, so activation tensors of any size (> 4 GiB at large per-GPU batches) stay on
+  // the fast path (the host checks the per-tile span, dispatch_tiles).
+  const uint32_t n_tile0 = fdiv((uint32_t)m0, p.div_ohow);
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T) +
+                                (size_t)n_tile0 * p.IH * p.IW * p.lda * sizeof(T);
   const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)blockIdx.y * p.b_gstride * sizeof(T);
 
   // ---- per-thread gather state: rows are fixed for the whole K loop -----------------------
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
       const uint32_t ox = rem - oy * p.div_ow.d;
       iy0[i] = oy * p.SY;
       ix0[i] = ox * p.SX;
-      pbase[i] = n * p.IH * p.IW;
+      pbase[i] = (n - n_tile0) * p.IH * p.IW;
     } else {
       iy0[i] = -(1 << 28);
       ix0[i] = 0;
@@ -555,10 +560,14 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
   const int mt = lid / tiles_n, nt = lid - mt * tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T);
+  const int x0 = __builtin_amdgcn_readfirstlane(p.taps[1]);        // dx of the first tap of every group
+  // gather base = first image of the staged pixel range (see igemm_kernel): 32-bit offsets span one tile only
+  const long q_first = (long)m0 + x0;
+  const uint32_t n_tile0 = fdiv((uint32_t)(q_first > 0 ? q_first : 0), p.div_ohow);
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)blockIdx.y * p.a_gstride * sizeof(T) +
+                                (size_t)n_tile0 * p.IH * p.IW * p.lda * sizeof(T);
   const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)blockIdx.y * p.b_gstride * sizeof(T);
 
-  const int x0 = __builtin_amdgcn_readfirstlane(p.taps[1]);        // dx of the first tap of every group
   const int ngroups = p.ntaps / 3;
   const int kpt = p.Cred / BK;
 
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
       const uint32_t oy = fdiv(rem, p.div_ow);
       const uint32_t ox = rem - oy * p.div_ow.d;
       oys[i] = (int)oy * p.SY;
-      pixb[i] = (int)(n * p.IH * p.IW + ox);
+      pixb[i] = (int)((n - n_tile0) * p.IH * p.IW + ox);
     } else {
       oys[i] = 0;
       pixb[i] = -1;
@@ -1032,14 +1041,19 @@ int choose_cfg(int M, int N, int Cred, int ntaps, int esize, bool ext) {
   return wide ? 2 : 3;   // also the non-aligned gather (64-byte K tiles)
 }
 
+// The aligned kernels address the activation with 32-bit byte offsets from the first image of their tile: the images a
+// tile of <= 256 (+2) output pixels can touch must span less than 4 GiB.  (The tensor itself may be any size.)
+bool tile_span_fits32(long ohow, int IH, int IW, int lda, int es) {
+  const double images = 258.0 / (double)(ohow > 0 ? ohow : 1) + 2.0;
+  return images * IH * IW * lda * es < 4294967296.0;
+}
+
 template <typename T, typename TOut>
 void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
   constexpr int ES = (int)sizeof(T);
   constexpr bool EXT = sizeof(T) == 2 && std::is_same<T, TOut>::value;   // tuning hook applies here only
   // the aligned kernels address both operands with 32-bit byte offsets
-  const long nb = p.M / (long)p.div_ohow.d + 1;
-  const bool fits32 = (double)nb * p.IH * p.IW * p.lda * ES < 4294967296.0 &&
-                      (double)p.N * p.ldb * ES < 4294967296.0;
+  const bool fits32 = tile_span_fits32(p.div_ohow.d, p.IH, p.IW, p.lda, ES) && (double)p.N * p.ldb * ES < 4294967296.0;
   const bool aligned = p.Cred % (64 / ES) == 0 && fits32;
   const int cfg = choose_cfg(p.M, p.N, p.Cred, p.ntaps, ES, EXT);
   if (p.flags & kIgemmAxf) {
@@ -1179,11 +1193,11 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
   DPA_CHECK_HIP(hipGetLastError());
 }
 
-bool igemm_axf_ok(long NB, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups) {
+bool igemm_axf_ok(long ohow, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups) {
   if (dtype == kF32 || dtype != out_dtype || groups > 1) return false;
   const int es = 2;
   if (Cred % (64 / es) != 0 || Cred > kAxfMaxCred) return false;
-  return (double)(NB + 1) * IH * IW * lda * es < 4294967296.0 && (double)N * ldb * es < 4294967296.0;
+  return tile_span_fits32(ohow, IH, IW, lda, es) && (double)N * ldb * es < 4294967296.0;
 }
 
 int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype) {

@@ -49,7 +49,7 @@ struct IgemmParams {
 };
 void igemm_launch(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
 // whether a launch of this shape can take kIgemmAxf (the caller materialises the activation otherwise)
-bool igemm_axf_ok(long NB, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups);
+bool igemm_axf_ok(long ohow, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups);
 int igemm_tile_m(int dtype);
 // rows of the per-tile BatchNorm statistics slab the launch for this problem will write
 int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype);

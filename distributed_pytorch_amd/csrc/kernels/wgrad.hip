@@ -97,13 +97,17 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   // left every workgroup waiting a full memory latency per 8 MFMAs)
   uint4 rp[PF][P_IT], rq[PF][Q_IT];
   uint32_t poff[P_IT], qoff[Q_IT], pmask[PF][P_IT], qmask[PF][Q_IT];
+  // LIN: 32-bit byte offsets relative to the first pixel of THIS workgroup's split (64-bit bases), so only one split's
+  // rows have to span less than 4 GiB (host checked) -- the tensors themselves may be any size
+  const char* __restrict__ Yl = Yg + (LIN ? (size_t)m_begin * p.ldy * sizeof(T) : (size_t)0);
+  const char* __restrict__ Xl = Xg + (LIN ? (size_t)m_begin * p.ldx * sizeof(T) : (size_t)0);
   if (LIN) {
 #pragma unroll
     for (int i = 0; i < P_IT; ++i)
-      poff[i] = (uint32_t)(((uint32_t)(m_begin + (tid + i * NT) / CPP) * (uint32_t)p.ldy + i0 + cp * VEC) * sizeof(T));
+      poff[i] = (uint32_t)(((uint32_t)((tid + i * NT) / CPP) * (uint32_t)p.ldy + i0 + cp * VEC) * sizeof(T));
 #pragma unroll
     for (int i = 0; i < Q_IT; ++i)
-      qoff[i] = (uint32_t)(((uint32_t)(m_begin + (tid + i * NT) / CPQ) * (uint32_t)p.ldx + kcol) * sizeof(T));
+      qoff[i] = (uint32_t)(((uint32_t)((tid + i * NT) / CPQ) * (uint32_t)p.ldx + kcol) * sizeof(T));
   }
   const uint32_t pstep = (uint32_t)(BKP * p.ldy * (int)sizeof(T)), qstep = (uint32_t)(BKP * p.ldx * (int)sizeof(T));
   // generic gather: incremental pixel coordinates of the rows this thread stages
@@ -120,14 +124,14 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
       for (int i = 0; i < P_IT; ++i) {
         const bool ok = pok && m_base + (tid + i * NT) / CPP < m_end;
         pmask[S][i] = ok ? 0xffffffffu : 0u;
-        rp[S][i] = *reinterpret_cast<const uint4*>(Yg + (ok ? poff[i] : 0u));
+        rp[S][i] = *reinterpret_cast<const uint4*>(Yl + (ok ? poff[i] : 0u));
         poff[i] += pstep;
       }
 #pragma unroll
       for (int i = 0; i < Q_IT; ++i) {
         const bool ok = qok && m_base + (tid + i * NT) / CPQ < m_end;
         qmask[S][i] = ok ? 0xffffffffu : 0u;
-        rq[S][i] = *reinterpret_cast<const uint4*>(Xg + (ok ? qoff[i] : 0u));
+        rq[S][i] = *reinterpret_cast<const uint4*>(Xl + (ok ? qoff[i] : 0u));
         qoff[i] += qstep;
       }
       return;
@@ -364,10 +368,10 @@ void launch_cfg_x(const WgradParams& p, hipStream_t stream) {
   constexpr int lds = 2 * BKP * ((BI + BJ) * (int)sizeof(T) + 128);
   const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
   const int es = (int)sizeof(T);
-  const long nb = p.M / (long)p.div_ohow.d + 1;
   const bool lin = p.ntaps == 1 && p.SY == 1 && p.SX == 1 && p.taps_zero &&
                    (long)p.div_ohow.d == (long)p.IH * p.IW && (int)p.div_ow.d == p.IW &&
-                   (double)p.M * p.ldy * es < 4294967296.0 && (double)nb * p.IH * p.IW * p.ldx * es < 4294967296.0;
+                   ((double)p.pix_per_split + 2.0 * BKP) * p.ldy * es < 4294967296.0 &&
+                   ((double)p.pix_per_split + 2.0 * BKP) * p.ldx * es < 4294967296.0;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, KB, WI, WJ, false, PF, XF>),

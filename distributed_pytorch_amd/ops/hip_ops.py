@@ -520,8 +520,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
         tt = _tap_table(dy.device, taps)
         scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
         slab = None
-        if bnred is not None and scatter is None and len(classes) == 1 and K % 32 == 0 \
-                and dy.numel() < (1 << 30) and dx.numel() < (1 << 30):
+        if bnred is not None and scatter is None and len(classes) == 1 and K % 32 == 0:
             rows = C().igemm_stats_rows(NB * SH * SW, Cx, K, len(taps), _dt(dy), _dt(dy))
             slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
         _igemm(dy, wt, dx, None, slab, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
@@ -629,7 +628,9 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
         NB, IH, IW, Cx = x.shape
         ok = getattr(x, "_dpa_deferred_relu", False) and not skip and x.is_contiguous() and Cx == Cw \
             and _axf_redundancy(K, weight.shape[2], weight.shape[3], stride) <= _AXF_MAX_RED \
-            and C().igemm_axf_ok(NB, IH, IW, Cx, K, Cx, weight.shape[2] * weight.shape[3] * Cx, _dt(x), _dt(x), 1)
+            and C().igemm_axf_ok(_conv_out(IH, weight.shape[2], stride[0], padding[0])
+                                 * _conv_out(IW, weight.shape[3], stride[1], padding[1]), IH, IW, Cx, K, Cx,
+                                 weight.shape[2] * weight.shape[3] * Cx, _dt(x), _dt(x), 1)
         if not ok:
             x, axf = materialize(x), None
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),

@@ -12,15 +12,12 @@ pytestmark = pytest.mark.gpu
 from distributed_pytorch_amd.ops import functional as F  # noqa: E402
 
 DEV = "cuda"
-TOL = {torch.float32: (2e-4, 2e-4), torch.bfloat16: (2e-2, 2e-2), torch.float16: (4e-3, 4e-3)}
+from _gpu_util import assert_close  # noqa: E402
 
 
 def _close(a, b, dtype, scale=1.0, what=""):
-    rtol, atol = TOL[dtype]
-    a, b = a.float().cpu(), b.float().cpu()
-    err = (a - b).abs().max().item()
-    ref = b.abs().max().item()
-    assert err <= atol * scale * max(ref, 1.0) + rtol * ref * 0, "%s: max err %g vs ref max %g" % (what, err, ref)
+    """Per element |a - b| <= atol * rms(b) + rtol * |b| AND a relative-Frobenius bound (tests/_gpu_util.py)."""
+    assert_close(a, b, dtype, what=what, scale=scale)
 
 
 def _slab_m2(stats):
