@@ -338,6 +338,11 @@ PYBIND11_MODULE(_C, m) {
   m.def("transpose_ktc", [](uintptr_t w, uintptr_t wt, int K, int T, int C, int in_dtype, int out_dtype, uintptr_t s) {
     transpose_ktc_launch(ptr<const void>(w), ptr<void>(wt), K, T, C, in_dtype, out_dtype, st(s));
   });
+  m.def("shuffle_pair", [](uintptr_t a, uintptr_t b, uintptr_t o0, uintptr_t o1, long rows, int bf, int P, int backward,
+                           int dtype, uintptr_t s) {
+    shuffle_pair_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(o0), ptr<void>(o1), rows, bf, P, backward, dtype,
+                        st(s));
+  });
   m.def("copy_rows", [](uintptr_t src, long ld_src, uintptr_t dst, long ld_dst, long rows, long row_bytes, uintptr_t s) {
     copy_rows_launch(ptr<const void>(src), ld_src, ptr<void>(dst), ld_dst, rows, row_bytes, st(s));
   });

@@ -349,6 +349,51 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint4* __restrict_
   }
 }
 
+// ShuffleNetV2 channel shuffle (groups = 2) fused with the channel split that always follows it.  A stage's activation
+// lives as a PAIR of tensors (left, right), each [rows][P] with `bf` real channels and P - bf zero pad channels (P = bf
+// rounded up to 16-byte vectors: ShuffleNetV2 x1.0 / x2.0 have 58 / 122-channel halves).
+//   forward : out = shuffle(cat(A, B)), out[2i] = A[i], out[2i+1] = B[i]; (Lo, Ro) = (out[:bf], out[bf:])
+//   backward: the inverse permutation of (dLo, dRo) back to (dA, dB)
+// One thread per 16-byte output chunk; the scattered 2/4-byte reads hit rows that are resident in L2.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void shuffle_pair_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                           T* __restrict__ o0, T* __restrict__ o1, long rows, int bf,
+                                                           int P) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int chunks = P / VEC;
+  const long total = rows * chunks * 2;
+  const int h = bf / 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r2 = i / chunks;
+    const int ck = (int)(i - r2 * chunks);
+    const int which = (int)(r2 & 1);          // output tensor 0 / 1
+    const long r = r2 >> 1;
+    const T* ra = a + r * P;
+    const T* rb = b + r * P;
+    T v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = ck * VEC + j;
+      T t = from_float<T>(0.f);
+      if (c < bf) {
+        if (!BWD) {            // out channel (which * bf + c) of the shuffled tensor
+          const int src = (c >> 1) + which * h;
+          t = (c & 1) ? rb[src] : ra[src];
+        } else {               // which 0: dA[c], which 1: dB[c]; shuffled index 2c + which lives in (a | b) = (dLo | dRo)
+          const int s = 2 * c + which;
+          t = s < bf ? ra[s] : rb[s - bf];
+        }
+      }
+      v[j] = t;
+    }
+    T* dst = (which ? o1 : o0) + r * P + ck * VEC;
+    uint4 w;
+    __builtin_memcpy(&w, v, 16);
+    *reinterpret_cast<uint4*>(dst) = w;
+  }
+}
+
 #define DPA_DISPATCH_2(di, dout, ...)                                                        \
   DPA_DISPATCH_DTYPE(di, { using TI = T; DPA_DISPATCH_DTYPE(dout, { using TO = T; __VA_ARGS__; }) })
 
@@ -488,6 +533,22 @@ void copy_rows_launch(const void* src, long ld_src_bytes, void* dst, long ld_dst
   const int chunks = (int)(row_bytes / 16);
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * chunks)), dim3(256), 0, s, (const uint4*)src,
                      ld_src_bytes / 16, (uint4*)dst, ld_dst_bytes / 16, rows, chunks);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void shuffle_pair_launch(const void* a, const void* b, void* o0, void* o1, long rows, int bf, int P, int backward,
+                         int dtype, hipStream_t s) {
+  const int vec = dtype == kF32 ? 4 : 8;
+  if (rows <= 0) return;
+  if (P % vec || bf > P || bf <= 0 || (bf & 1)) throw std::invalid_argument("shuffle_pair: bad channel counts");
+  const long total = rows * (P / vec) * 2;
+  if (backward) {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shuffle_pair_kernel<T, true>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)a, (const T*)b, (T*)o0, (T*)o1, rows, bf, P));
+  } else {
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shuffle_pair_kernel<T, false>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 (const T*)a, (const T*)b, (T*)o0, (T*)o1, rows, bf, P));
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 

@@ -227,6 +227,10 @@ void transpose_ktc_launch(const void* w, void* wt, int K, int T, int C, int in_d
                           hipStream_t s);
 void axpby_launch(const void* x, int x_dtype, float* y, long n, float alpha, float beta, hipStream_t s);
 void fill_launch(void* p, long nbytes, int value, hipStream_t s);
+// ShuffleNetV2: (o0, o1) = split(channel_shuffle(cat(a, b), groups = 2)) on [rows][P] tensors with bf real channels
+// (the rest zero padding); backward != 0: the inverse permutation (a, b = gradients of o0, o1 -> gradients of a, b)
+void shuffle_pair_launch(const void* a, const void* b, void* o0, void* o1, long rows, int bf, int P, int backward,
+                         int dtype, hipStream_t s);
 // strided 2-D copy in 16-byte chunks: channel concat / split of NHWC activations
 void copy_rows_launch(const void* src, long ld_src_bytes, void* dst, long ld_dst_bytes, long rows, long row_bytes,
                       hipStream_t s);

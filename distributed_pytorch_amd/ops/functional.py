@@ -175,6 +175,19 @@ def cat_channels(xs) -> torch.Tensor:
     return torch.cat(xs, dim=-1)
 
 
+def shuffle_pair(a: torch.Tensor, b: torch.Tensor, bf: int):
+    """ShuffleNetV2's ``channel_shuffle(cat(a, b), groups=2)`` followed by the ``chunk(2)`` of the next block, as one op:
+    returns the two halves.  ``a`` / ``b`` hold ``bf`` real channels (+ zero padding up to their width on the GPU)."""
+    if _on_gpu(a):
+        return _hip().shuffle_pair(a, b, bf)
+    out = torch.stack([a[..., :bf], b[..., :bf]], dim=-1).flatten(-2)        # out[2i] = a[i], out[2i+1] = b[i]
+    lo, ro = out[..., :bf], out[..., bf:]
+    pad = a.shape[-1] - bf
+    if pad:
+        lo, ro = TF.pad(lo, (0, pad)), TF.pad(ro, (0, pad))
+    return lo.contiguous(), ro.contiguous()
+
+
 def adaptive_avg_pool2d(x: torch.Tensor, output_size) -> torch.Tensor:
     o = _pair(output_size)
     if _on_gpu(x):

@@ -1417,6 +1417,41 @@ def cat_channels(xs):
     return _CatFn.apply(*xs)
 
 
+class _ShufflePairFn(torch.autograd.Function):
+    """(L', R') = split(channel_shuffle(cat(a, b), 2)) on padded halves (``elementwise.hip: shuffle_pair_kernel``)."""
+
+    @staticmethod
+    def forward(ctx, a, b, bf):
+        a = a if a.is_contiguous() else a.contiguous()
+        b = b if b.is_contiguous() else b.contiguous()
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise ValueError("shuffle_pair: the two halves must have the same shape and dtype")
+        P = a.shape[-1]
+        o0, o1 = torch.empty_like(a), torch.empty_like(a)
+        C().shuffle_pair(a.data_ptr(), b.data_ptr(), o0.data_ptr(), o1.data_ptr(), a.numel() // P, bf, P, 0, _dt(a),
+                         _stream())
+        ctx.bf = bf
+        return o0, o1
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        if d0 is None:
+            d0 = torch.zeros_like(d1)
+        if d1 is None:
+            d1 = torch.zeros_like(d0)
+        d0 = d0 if d0.is_contiguous() else d0.contiguous()
+        d1 = d1 if d1.is_contiguous() else d1.contiguous()
+        P = d0.shape[-1]
+        da, db = torch.empty_like(d0), torch.empty_like(d0)
+        C().shuffle_pair(d0.data_ptr(), d1.data_ptr(), da.data_ptr(), db.data_ptr(), d0.numel() // P, ctx.bf, P, 1,
+                         _dt(d0), _stream())
+        return da, db, None
+
+
+def shuffle_pair(a, b, bf):
+    return _ShufflePairFn.apply(a, b, int(bf))
+
+
 class _AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, o):

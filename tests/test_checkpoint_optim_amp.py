@@ -21,7 +21,9 @@ def test_param_counts_and_torchvision_key_names():
             "googlenet": 6624904, "regnet_x_400mf": 5495976, "regnet_x_1_6gf": 9190136, "regnet_x_8gf": 39572648,
             "regnet_y_400mf": 4344144, "regnet_y_1_6gf": 11202430, "mobilenet_v3_large": 5483032,
             "mobilenet_v3_small": 2542856, "efficientnet_b0": 5288548, "efficientnet_b3": 12233232,
-            "efficientnet_v2_s": 21458488, "inception_v3": 23834568, "convnext_tiny": 28589128}
+            "efficientnet_v2_s": 21458488, "inception_v3": 23834568, "convnext_tiny": 28589128,
+            "shufflenet_v2_x0_5": 1366792, "shufflenet_v2_x1_0": 2278604, "shufflenet_v2_x1_5": 3503624,
+            "shufflenet_v2_x2_0": 7393996}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch

@@ -26,7 +26,9 @@ def _run(model, x, t):
                                            ("googlenet", 96, 3e-3), ("regnet_x_400mf", 96, 4e-3),
                                            ("regnet_y_400mf", 96, 4e-3), ("mobilenet_v3_small", 96, 4e-3),
                                            ("mobilenet_v3_large", 64, 4e-3), ("efficientnet_b0", 64, 4e-3),
-                                           ("efficientnet_v2_s", 64, 4e-3), ("inception_v3", 171, 6e-3), ("convnext_tiny", 64, 4e-3)])
+                                           ("efficientnet_v2_s", 64, 4e-3), ("inception_v3", 171, 6e-3), ("convnext_tiny", 64, 4e-3),
+                                           ("shufflenet_v2_x0_5", 96, 4e-3), ("shufflenet_v2_x1_0", 96, 4e-3),
+                                           ("shufflenet_v2_x2_0", 64, 4e-3)])
 def test_fp32_model_matches_cpu_reference(arch, size, tol):
     from distributed_pytorch_amd import amp, models
 

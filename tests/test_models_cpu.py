@@ -10,7 +10,7 @@ from distributed_pytorch_amd.ops import functional as F
 FAMILIES = [("resnet18", 64), ("resnext50_32x4d", 64), ("alexnet", 96), ("vgg11_bn", 32), ("squeezenet1_1", 64),
             ("densenet121", 64), ("mobilenet_v2", 64), ("mobilenet_v3_small", 64), ("mnasnet0_5", 64), ("googlenet", 64),
             ("inception_v3", 107), ("regnet_x_400mf", 64), ("regnet_y_400mf", 64), ("efficientnet_b0", 64),
-            ("efficientnet_v2_s", 64), ("convnext_tiny", 64)]
+            ("efficientnet_v2_s", 64), ("convnext_tiny", 64), ("shufflenet_v2_x1_0", 64)]
 
 
 @pytest.mark.parametrize("arch,size", FAMILIES)
@@ -31,7 +31,7 @@ def test_family_trains_one_step_on_cpu(arch, size):
 
 def test_registry_is_the_arch_choice_list():
     names = models.list_models()
-    assert len(names) == 64 and names == sorted(names)
+    assert len(names) == 68 and names == sorted(names)
     for fam in ("resnet50", "vgg16_bn", "densenet201", "mobilenet_v3_large", "efficientnet_b7", "efficientnet_v2_l",
                 "regnet_y_128gf", "convnext_large", "inception_v3", "googlenet", "mnasnet1_3", "squeezenet1_0",
                 "wide_resnet101_2", "resnext101_64x4d"):
@@ -60,3 +60,24 @@ def test_new_functional_ops_cpu_reference():
     ref = TF.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1)
     assert torch.allclose(F.avg_pool2d(x, 3, 1, 1), ref)
     assert F.avg_pool2d(x[:, :4], 2, 2).shape == (2, 2, 3, 16)
+
+
+def test_shufflenet_padded_channel_layout_equals_the_plain_one():
+    """ShuffleNetV2 x1.0 has 58 / 116-channel halves; on the GPU they are stored zero-padded to 16-byte vectors and the
+    parameters are scattered into that layout.  The same code path on the CPU backend must give the logits, the
+    running statistics and every parameter gradient of the unpadded model."""
+    torch.manual_seed(3)
+    a = models.create_model("shufflenet_v2_x1_0", num_classes=5).train()
+    b = models.create_model("shufflenet_v2_x1_0", num_classes=5).train()
+    b.load_state_dict(a.state_dict())
+    b.force_vec = 8
+    x = torch.randn(2, 3, 64, 64)
+    t = torch.randint(0, 5, (2,))
+    la, lb = a(x), b(x)
+    assert torch.allclose(la, lb, atol=1e-5), (la - lb).abs().max()
+    F.cross_entropy(la, t).backward()
+    F.cross_entropy(lb, t).backward()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert q.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-5, rtol=1e-4), n
+    for (n, u), v in zip(a.named_buffers(), b.buffers()):
+        assert torch.allclose(u.float(), v.float(), atol=1e-5), n
