@@ -338,6 +338,30 @@ PYBIND11_MODULE(_C, m) {
   m.def("transpose_ktc", [](uintptr_t w, uintptr_t wt, int K, int T, int C, int in_dtype, int out_dtype, uintptr_t s) {
     transpose_ktc_launch(ptr<const void>(w), ptr<void>(wt), K, T, C, in_dtype, out_dtype, st(s));
   });
+  m.def("attn_max_tokens", &attn_max_tokens);
+  m.def("window_partition", [](uintptr_t src, uintptr_t dst, int reverse, int B, int H, int W, int C, int wh, int ww, int nh,
+                               int nw, int sh, int sw, int grid_mode, int dtype, uintptr_t s) {
+    window_partition_launch(ptr<const void>(src), ptr<void>(dst), reverse, B, H, W, C, wh, ww, nh, nw, sh, sw, grid_mode,
+                            dtype, st(s));
+  });
+  m.def("qk_normalize", [](uintptr_t x, uintptr_t dy, uintptr_t out, uintptr_t mult, uintptr_t inv, uintptr_t dmult_part,
+                           long tokens, int H, int D, int backward, int dtype, uintptr_t s) {
+    qk_normalize_launch(ptr<const void>(x), ptr<const void>(dy), ptr<void>(out), ptr<const float>(mult), ptr<float>(inv),
+                        ptr<float>(dmult_part), tokens, H, D, backward, dtype, st(s));
+  });
+  m.def("attn_dbias_splits", &attn_dbias_splits);
+  m.def("attn_fwd", [](uintptr_t qkv, uintptr_t out, uintptr_t lse, uintptr_t bias, int nbias, uintptr_t scale, int B, int H,
+                       int S, int D, int dtype, uintptr_t s) {
+    attn_fwd_launch(ptr<const void>(qkv), ptr<void>(out), ptr<float>(lse), ptr<const float>(bias), nbias,
+                    ptr<const float>(scale), B, H, S, D, dtype, st(s));
+  });
+  m.def("attn_bwd", [](uintptr_t qkv, uintptr_t out, uintptr_t dout, uintptr_t lse, uintptr_t delta, uintptr_t bias,
+                       int nbias, uintptr_t scale, uintptr_t dqkv, uintptr_t dbias, int nsplit, int B, int H, int S, int D,
+                       int dtype, uintptr_t s) {
+    attn_bwd_launch(ptr<const void>(qkv), ptr<const void>(out), ptr<const void>(dout), ptr<const float>(lse),
+                    ptr<float>(delta), ptr<const float>(bias), nbias, ptr<const float>(scale), ptr<void>(dqkv),
+                    ptr<float>(dbias), nsplit, B, H, S, D, dtype, st(s));
+  });
   m.def("shuffle_pair", [](uintptr_t a, uintptr_t b, uintptr_t o0, uintptr_t o1, long rows, int bf, int P, int backward,
                            int dtype, uintptr_t s) {
     shuffle_pair_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(o0), ptr<void>(o1), rows, bf, P, backward, dtype,

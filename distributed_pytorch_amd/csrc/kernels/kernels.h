@@ -235,6 +235,27 @@ void shuffle_pair_launch(const void* a, const void* b, void* o0, void* o1, long 
 void copy_rows_launch(const void* src, long ld_src_bytes, void* dst, long ld_dst_bytes, long rows, long row_bytes,
                       hipStream_t s);
 
+// ------------------------------------------------------------------------------ attention.hip
+// O = softmax(scale[h] * Q K^T + bias[b % nbias][h]) V on the packed projection qkv [B][S][3][H][D] (bf16 / f16);
+// out [B][S][H][D], lse [B][H][S] fp32.  bias: optional fp32 [nbias][H][S][S].
+int attn_max_tokens(int D);
+// x [B][H][W][C] <-> windows [B*nh*nw][wh*ww][C] (zero padding up to nh*wh x nw*ww, cyclic shift (sh, sw) for Swin;
+// grid_mode: MaxViT's grid partition, token (i, j) of window (gh, gw) = pixel (i*nh + gh, j*nw + gw))
+void window_partition_launch(const void* src, void* dst, int reverse, int B, int H, int W, int C, int wh, int ww, int nh,
+                             int nw, int sh, int sw, int grid_mode, int dtype, hipStream_t s);
+// Swin V2 cosine attention: q <- mult[h] * q / |q|, k <- k / |k| on the packed [tokens][3][H][D] projection (v copied);
+// inv [tokens][2][H] keeps the inverse norms; backward also writes dmult_part [tokens][H] (sum over tokens = d mult)
+void qk_normalize_launch(const void* x, const void* dy, void* out, const float* mult, float* inv, float* dmult_part,
+                         long tokens, int H, int D, int backward, int dtype, hipStream_t s);
+void attn_fwd_launch(const void* qkv, void* out, float* lse, const float* bias, int nbias, const float* scale, int B,
+                     int H, int S, int D, int dtype, hipStream_t s);
+// dqkv [B][S][3][H][D]; delta: fp32 scratch [B][H][S]; dbias (optional, S <= 64): partial slabs [nsplit][H][S][S] of the
+// gradient of the pre-softmax logits summed over the batch (fold with slab_reduce_launch)
+int attn_dbias_splits(int B, int H);
+void attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                     const float* bias, int nbias, const float* scale, void* dqkv, float* dbias, int nsplit, int B, int H,
+                     int S, int D, int dtype, hipStream_t s);
+
 // ------------------------------------------------------------------------------ optim.hip
 struct SgdTensor {   // one entry per parameter tensor (device table)
   float* p;          // fp32 master / parameter

@@ -205,7 +205,7 @@ LnPlan ln_plan(long rows, int C, int dtype) {
   const int vec = dtype == kF32 ? 4 : 8;
   if (C <= 0 || C % vec != 0) throw std::invalid_argument("layer_norm: C must fill 16-byte vectors");
   const int chunks = C / vec;
-  if (chunks > 256) throw std::invalid_argument("layer_norm: C too large (max 256 16-byte chunks per row)");
+  if (chunks > 512) throw std::invalid_argument("layer_norm: C too large (max 512 16-byte chunks per row)");
   LnPlan p;
   if (chunks <= 64) {
     p.G = 4;
@@ -213,7 +213,7 @@ LnPlan ln_plan(long rows, int C, int dtype) {
     p.maxch = 1;
   } else {
     p.G = 64;
-    p.maxch = chunks <= 128 ? 2 : 4;
+    p.maxch = chunks <= 128 ? 2 : (chunks <= 256 ? 4 : 8);
   }
   const long rows_per_block = 4 * (64 / p.G);
   long b = (rows + rows_per_block - 1) / rows_per_block;
@@ -235,7 +235,8 @@ void ln_fwd_launch(const void* x, const float* w, const float* b, void* y, float
                                                b, (T*)y, mean, rstd, rows, C, p.G, eps))
   if (p.maxch == 1) { DPA_LN_FWD(1); }
   else if (p.maxch == 2) { DPA_LN_FWD(2); }
-  else { DPA_LN_FWD(4); }
+  else if (p.maxch == 4) { DPA_LN_FWD(4); }
+  else { DPA_LN_FWD(8); }
 #undef DPA_LN_FWD
   DPA_CHECK_HIP(hipGetLastError());
 }
@@ -251,7 +252,8 @@ void ln_bwd_launch(const void* dy, const void* x, const float* w, const float* m
                                                (const T*)x, w, mean, rstd, (T*)dx, partial, rows, C, p.G))
   if (p.maxch == 1) { DPA_LN_BWD(1); }
   else if (p.maxch == 2) { DPA_LN_BWD(2); }
-  else { DPA_LN_BWD(4); }
+  else if (p.maxch == 4) { DPA_LN_BWD(4); }
+  else { DPA_LN_BWD(8); }
 #undef DPA_LN_BWD
   hipLaunchKernelGGL(ln_fold_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, s, partial, p.blocks, C, dgamma, dbeta,
                      beta_w, beta_b);

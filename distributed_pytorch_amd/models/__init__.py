@@ -16,9 +16,11 @@ from . import regnet as _rg
 from . import resnet as _rn
 from . import shufflenet as _sh
 from . import squeezenet as _sq
+from . import swin as _sw
+from . import vit as _vt
 
 _REGISTRY: Dict[str, Callable] = {}
-for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in, _cx, _sh):
+for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in, _cx, _sh, _vt, _sw):
     for _name in dir(_mod):
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("_") and callable(_fn) \

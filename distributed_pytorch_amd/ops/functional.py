@@ -175,6 +175,89 @@ def cat_channels(xs) -> torch.Tensor:
     return torch.cat(xs, dim=-1)
 
 
+def attention(qkv: torch.Tensor, num_heads: int, scale, rel_bias: Optional[torch.Tensor] = None,
+              mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Multi-head self-attention on the packed projection: ``qkv`` is ``[B, S, 3 * H * D]`` laid out ``[3][H][D]`` per
+    token (what ``nn.MultiheadAttention``'s in-projection, Swin's and MaxViT's ``qkv`` Linear produce), the result
+    ``[B, S, H * D]`` feeds the output projection.
+
+        softmax(scale * q k^T + rel_bias[h] + mask[b % nW]) v
+
+    ``scale``: a float or a per-head tensor ``[H]`` (not differentiated here).  ``rel_bias``: optional learnable
+    ``[H, S, S]`` (Swin / MaxViT relative position bias; gets a gradient).  ``mask``: optional constant ``[nW, S, S]``
+    (Swin's shifted-window mask), batch entry ``b`` uses window ``b % nW``.  On the GPU this is one fused MFMA kernel
+    per direction (``csrc/kernels/attention.hip``): the scores never reach memory."""
+    if _on_gpu(qkv):
+        return _hip().attention(qkv, num_heads, scale, rel_bias, mask)
+    B, S, W3 = qkv.shape
+    H = num_heads
+    D = W3 // (3 * H)
+    q, k, v = qkv.reshape(B, S, 3, H, D).permute(2, 0, 3, 1, 4).float().unbind(0)      # [B, H, S, D]
+    sc = scale.float().reshape(1, H, 1, 1) if isinstance(scale, torch.Tensor) else float(scale)
+    att = (q @ k.transpose(-1, -2)) * sc
+    if rel_bias is not None:
+        att = att + rel_bias.float().reshape(1, H, S, S)
+    if mask is not None:
+        nW = mask.shape[0]
+        att = (att.reshape(B // nW, nW, H, S, S) + mask.float().reshape(1, nW, 1, S, S)).reshape(B, H, S, S)
+    out = att.softmax(-1) @ v
+    return out.transpose(1, 2).reshape(B, S, H * D).to(qkv.dtype)
+
+
+def window_geometry(B: int, H: int, W: int, wh: int, ww: int, sh: int = 0, sw: int = 0, grid: bool = False):
+    """Geometry tuple of ``window_partition``: ``(B, H, W, wh, ww, nh, nw, sh, sw, grid)``.  Window mode: windows of
+    ``wh x ww`` tokens over the image zero-padded to a multiple of the window, after a cyclic shift by ``(sh, sw)``
+    (Swin).  Grid mode (MaxViT): ``wh x ww`` is the GRID size, token ``(i, j)`` of window ``(gh, gw)`` is pixel
+    ``(i * nh + gh, j * nw + gw)``; the image must divide evenly."""
+    if grid:
+        if H % wh or W % ww:
+            raise ValueError("grid partition needs H, W divisible by the grid size")
+        return (B, H, W, wh, ww, H // wh, W // ww, 0, 0, True)
+    return (B, H, W, wh, ww, -(-H // wh), -(-W // ww), sh, sw, False)
+
+
+def window_partition(x: torch.Tensor, geom) -> torch.Tensor:
+    """``[B, H, W, C] -> [B * nh * nw, wh * ww, C]`` (shift + pad + partition in one gather on the GPU)."""
+    if _on_gpu(x):
+        return _hip().window_partition(x, geom, False)
+    B, H, W, wh, ww, nh, nw, sh, sw, grid = geom
+    C = x.shape[-1]
+    if grid:
+        return x.reshape(B, wh, nh, ww, nw, C).permute(0, 2, 4, 1, 3, 5).reshape(B * nh * nw, wh * ww, C)
+    x = TF.pad(x, (0, 0, 0, nw * ww - W, 0, nh * wh - H))
+    if sh or sw:
+        x = torch.roll(x, shifts=(-sh, -sw), dims=(1, 2))
+    return x.reshape(B, nh, wh, nw, ww, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nh * nw, wh * ww, C)
+
+
+def window_reverse(win: torch.Tensor, geom) -> torch.Tensor:
+    """Inverse of ``window_partition`` (the zero padding is dropped)."""
+    if _on_gpu(win):
+        return _hip().window_partition(win, geom, True)
+    B, H, W, wh, ww, nh, nw, sh, sw, grid = geom
+    C = win.shape[-1]
+    if grid:
+        return win.reshape(B, nh, nw, wh, ww, C).permute(0, 3, 1, 4, 2, 5).reshape(B, H, W, C)
+    x = win.reshape(B, nh, nw, wh, ww, C).permute(0, 1, 3, 2, 4, 5).reshape(B, nh * wh, nw * ww, C)
+    if sh or sw:
+        x = torch.roll(x, shifts=(sh, sw), dims=(1, 2))
+    return x[:, :H, :W, :].contiguous()
+
+
+def qk_normalize(qkv: torch.Tensor, mult: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """Swin V2 cosine attention pre-pass on the packed ``[.., 3 * H * D]`` projection: ``q <- mult[h] * q / |q|``,
+    ``k <- k / |k|`` (``F.normalize`` semantics, eps 1e-12), ``v`` unchanged.  Differentiable in ``qkv`` and ``mult``."""
+    if _on_gpu(qkv):
+        return _hip().qk_normalize(qkv, mult, num_heads)
+    shp = qkv.shape
+    H = num_heads
+    D = shp[-1] // (3 * H)
+    x = qkv.reshape(-1, 3, H, D).float()
+    q = TF.normalize(x[:, 0], dim=-1) * mult.float().reshape(1, H, 1)
+    k = TF.normalize(x[:, 1], dim=-1)
+    return torch.stack([q, k, x[:, 2]], dim=1).reshape(shp).to(qkv.dtype)
+
+
 def shuffle_pair(a: torch.Tensor, b: torch.Tensor, bf: int):
     """ShuffleNetV2's ``channel_shuffle(cat(a, b), groups=2)`` followed by the ``chunk(2)`` of the next block, as one op:
     returns the two halves.  ``a`` / ``b`` hold ``bf`` real channels (+ zero padding up to their width on the GPU)."""

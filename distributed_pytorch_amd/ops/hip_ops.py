@@ -1417,6 +1417,166 @@ def cat_channels(xs):
     return _CatFn.apply(*xs)
 
 
+# ------------------------------------------------------------------------------------------
+# fused multi-head self-attention (csrc/kernels/attention.hip)
+# ------------------------------------------------------------------------------------------
+_scale_vecs: Dict[tuple, torch.Tensor] = {}
+
+
+def _scale_vec(scale, H: int, device) -> torch.Tensor:
+    if isinstance(scale, torch.Tensor):
+        return scale.detach().float().reshape(H).contiguous()
+    key = (float(scale), H, device.index)
+    t = _scale_vecs.get(key)
+    if t is None:
+        t = _scale_vecs[key] = torch.full((H,), float(scale), dtype=torch.float32, device=device)
+    return t
+
+
+class _AttnFn(torch.autograd.Function):
+    """qkv [B, S, 3*H*D] -> [B, S, H*D].  fp32 activations run with fp16 MFMA operands and fp32 accumulation
+    (the kernel has no fp32 MFMA path; 11-bit operands, like TF32 elsewhere) -- bf16 / fp16 run natively."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, scale, rel_bias, mask):
+        B, S, W3 = qkv.shape
+        D = W3 // (3 * H)
+        in_dtype = qkv.dtype
+        q16 = qkv if qkv.is_contiguous() else qkv.contiguous()
+        if in_dtype == torch.float32:
+            q16 = q16.to(torch.float16)
+        dev = qkv.device
+        bias, nbias = None, 1
+        if rel_bias is not None:
+            bias = rel_bias.detach().float().reshape(1, H, S, S)
+            if mask is not None:
+                bias = bias + mask.detach().float().reshape(-1, 1, S, S)
+            bias = bias.contiguous()
+            nbias = bias.shape[0]
+        elif mask is not None:
+            bias = mask.detach().float().reshape(-1, 1, S, S).expand(-1, H, S, S).contiguous()
+            nbias = bias.shape[0]
+        if bias is not None and B % nbias:
+            raise ValueError("attention: batch %d is not a multiple of the %d mask windows" % (B, nbias))
+        sc = _scale_vec(scale, H, dev)
+        out = torch.empty((B, S, H * D), dtype=q16.dtype, device=dev)
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+        C().attn_fwd(q16.data_ptr(), out.data_ptr(), lse.data_ptr(), _p(bias), nbias, sc.data_ptr(), B, H, S, D,
+                     _dt(q16), _stream())
+        ctx.save_for_backward(q16, out, lse, bias, sc)
+        ctx.cfg = (H, D, nbias, in_dtype, rel_bias is not None and rel_bias.requires_grad,
+                   None if rel_bias is None else (rel_bias.shape, rel_bias.dtype))
+        return out if in_dtype == out.dtype else out.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q16, out, lse, bias, sc = ctx.saved_tensors
+        H, D, nbias, in_dtype, want_dbias, rb = ctx.cfg
+        B, S, _ = q16.shape
+        dev = q16.device
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        if dout.dtype != q16.dtype:
+            dout = dout.to(q16.dtype)
+        dqkv = torch.empty_like(q16)
+        delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+        slab, nsplit = None, 1
+        if want_dbias:
+            if S > 64:
+                raise ValueError("attention: a learnable bias is supported up to 64 tokens per window")
+            nsplit = C().attn_dbias_splits(B, H)
+            slab = torch.empty((nsplit, H, S, S), dtype=torch.float32, device=dev)
+        C().attn_bwd(q16.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), _p(bias), nbias,
+                     sc.data_ptr(), dqkv.data_ptr(), _p(slab), nsplit, B, H, S, D, _dt(q16), _stream())
+        dbias = None
+        if want_dbias:
+            dbias = torch.empty((H, S, S), dtype=torch.float32, device=dev)
+            C().slab_reduce(slab.data_ptr(), nsplit, H * S * S, dbias.data_ptr(), 0, 0.0, _stream())
+            dbias = dbias.reshape(rb[0]).to(rb[1])
+        if in_dtype != dqkv.dtype:
+            dqkv = dqkv.to(in_dtype)
+        return dqkv, None, None, dbias, None
+
+
+def attention(qkv, num_heads, scale, rel_bias=None, mask=None):
+    return _AttnFn.apply(qkv, int(num_heads), scale, rel_bias, mask)
+
+
+class _WindowFn(torch.autograd.Function):
+    """Window / grid partition of an NHWC token map and its inverse (``attention.hip: window_partition_kernel``);
+    each direction is the other's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, geom, reverse):
+        B, H, W, wh, ww, nh, nw, sh, sw, grid = geom
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[-1]
+        if reverse:
+            out = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+        else:
+            out = torch.empty((B * nh * nw, wh * ww, Cc), dtype=x.dtype, device=x.device)
+        C().window_partition(x.data_ptr(), out.data_ptr(), 1 if reverse else 0, B, H, W, Cc, wh, ww, nh, nw, sh, sw,
+                             1 if grid else 0, _dt(x), _stream())
+        ctx.cfg = (geom, reverse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        geom, reverse = ctx.cfg
+        return _WindowFn.apply(dy, geom, not reverse), None, None
+
+
+def window_partition(x, geom, reverse):
+    return _WindowFn.apply(x, tuple(geom), bool(reverse))
+
+
+class _QKNormFn(torch.autograd.Function):
+    """Swin V2 cosine attention pre-pass on the packed projection: q <- mult[h] * q / |q|, k <- k / |k|."""
+
+    @staticmethod
+    def forward(ctx, qkv, mult, H):
+        in_dtype = qkv.dtype
+        x = qkv if qkv.is_contiguous() else qkv.contiguous()
+        if in_dtype == torch.float32:
+            x = x.to(torch.float16)
+        tokens = x.numel() // x.shape[-1]
+        D = x.shape[-1] // (3 * H)
+        m = mult.detach().float().reshape(H).contiguous()
+        out = torch.empty_like(x)
+        inv = torch.empty((tokens, 2, H), dtype=torch.float32, device=x.device)
+        C().qk_normalize(x.data_ptr(), 0, out.data_ptr(), m.data_ptr(), inv.data_ptr(), 0, tokens, H, D, 0, _dt(x),
+                         _stream())
+        ctx.save_for_backward(x, m, inv)
+        ctx.cfg = (H, D, in_dtype, mult.shape, mult.dtype)
+        return out if in_dtype == out.dtype else out.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, m, inv = ctx.saved_tensors
+        H, D, in_dtype, mshape, mdtype = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        tokens = x.numel() // x.shape[-1]
+        dx = torch.empty_like(x)
+        part = torch.empty((tokens, H), dtype=torch.float32, device=x.device)
+        C().qk_normalize(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), m.data_ptr(), inv.data_ptr(), part.data_ptr(), tokens,
+                         H, D, 1, _dt(x), _stream())
+        dm = _colsum_f32(part).reshape(mshape).to(mdtype)
+        return (dx if in_dtype == dx.dtype else dx.to(in_dtype)), dm, None
+
+
+def _colsum_f32(part: torch.Tensor) -> torch.Tensor:
+    """Column sums of a small fp32 [rows, n] matrix in a fixed order (slab fold: rows are the slabs)."""
+    rows, n = part.shape
+    out = torch.empty(n, dtype=torch.float32, device=part.device)
+    C().slab_reduce(part.data_ptr(), rows, n, out.data_ptr(), 0, 0.0, _stream())
+    return out
+
+
+def qk_normalize(qkv, mult, num_heads):
+    return _QKNormFn.apply(qkv, mult, int(num_heads))
+
+
 class _ShufflePairFn(torch.autograd.Function):
     """(L', R') = split(channel_shuffle(cat(a, b), 2)) on padded halves (``elementwise.hip: shuffle_pair_kernel``)."""
 

@@ -192,3 +192,49 @@ def test_conv_epilogue_statistics_at_mean_1000_std(kind):
     yref = (y.double() - mean) / (var + 1e-5).sqrt()
     assert (out.double() - yref).abs().max().item() < 2e-3
     assert torch.allclose(rm.double(), 0.1 * mean, rtol=1e-6)
+
+
+# ---- fused attention --------------------------------------------------------------------------------------------
+ATTN_CASES = [
+    # B, S, H, D, bias, nW
+    (3, 197, 12, 64, False, 0),      # ViT-B/16
+    (5, 50, 12, 64, False, 0),       # ViT-B/32
+    (2, 257, 16, 80, False, 0),      # ViT-H/14: D = 80 (padded to 96 inside the kernel), 9 key blocks
+    (8, 49, 3, 32, True, 4),         # Swin-T stage 1, shifted windows
+    (6, 49, 24, 32, True, 0),        # Swin-T stage 4
+    (4, 64, 4, 32, True, 2),         # Swin-V2 window 8
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_fused_attention(case, dtype):
+    B, S, H, D, has_bias, nW = case
+    torch.manual_seed(51)
+    qkv = (torch.randn(B, S, 3 * H * D, device=DEV) * 0.8).to(dtype).requires_grad_(True)
+    rel = (torch.randn(H, S, S, device=DEV) * 0.5).requires_grad_(True) if has_bias else None
+    mask = None
+    if nW:
+        mask = torch.where(torch.rand(nW, S, S, device=DEV) < 0.2, -100.0, 0.0)
+        mask[:, torch.arange(S), torch.arange(S)] = 0.0
+    scale = torch.linspace(0.8, 1.2, H, device=DEV) * D ** -0.5
+    y = F.attention(qkv, H, scale, rel, mask)
+    gy = torch.randn(y.shape, device=DEV).to(dtype)
+    y.backward(gy)
+
+    qr = qkv.detach().float().requires_grad_(True)
+    rr = rel.detach().clone().requires_grad_(True) if has_bias else None
+    q, k, v = qr.reshape(B, S, 3, H, D).permute(2, 0, 3, 1, 4).unbind(0)
+    att = (q @ k.transpose(-1, -2)) * scale.reshape(1, H, 1, 1)
+    if has_bias:
+        att = att + rr[None]
+    if nW:
+        att = (att.reshape(B // nW, nW, H, S, S) + mask.reshape(1, nW, 1, S, S)).reshape(B, H, S, S)
+    yr = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, S, H * D)
+    yr.backward(gy.float())
+    # fp32 runs with fp16 operands; the probabilities pass through the operand dtype once more
+    cmp = torch.float16 if dtype == torch.float32 else dtype
+    assert_close(y, yr, cmp, what="out", scale=4 if dtype == torch.float32 else 2)
+    assert_close(qkv.grad, qr.grad, cmp, what="dqkv", scale=4)
+    if has_bias:
+        assert_close(rel.grad, rr.grad, cmp, what="dbias", scale=4)

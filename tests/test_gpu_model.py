@@ -28,7 +28,8 @@ def _run(model, x, t):
                                            ("mobilenet_v3_large", 64, 4e-3), ("efficientnet_b0", 64, 4e-3),
                                            ("efficientnet_v2_s", 64, 4e-3), ("inception_v3", 171, 6e-3), ("convnext_tiny", 64, 4e-3),
                                            ("shufflenet_v2_x0_5", 96, 4e-3), ("shufflenet_v2_x1_0", 96, 4e-3),
-                                           ("shufflenet_v2_x2_0", 64, 4e-3)])
+                                           ("shufflenet_v2_x2_0", 64, 4e-3),
+                                           ("vit_b_32", 224, 6e-3), ("swin_t", 64, 6e-3), ("swin_v2_t", 64, 6e-3)])
 def test_fp32_model_matches_cpu_reference(arch, size, tol):
     from distributed_pytorch_amd import amp, models
 
@@ -41,6 +42,10 @@ def test_fp32_model_matches_cpu_reference(arch, size, tol):
     for n, p in cpu.named_parameters():          # ConvNeXt's 1e-6 layer scale would hide the residual branches
         if n.endswith("layer_scale"):
             p.data.fill_(0.5)
+        if n == "heads.head.weight":             # ViT starts with a zero classifier: nothing would reach the encoder
+            torch.nn.init.normal_(p.data, std=0.02)
+        if n.endswith("relative_position_bias_table"):
+            torch.nn.init.normal_(p.data, std=0.5)
     gpu = copy.deepcopy(cpu).cuda()
     x = torch.randn(4, 3, size, size)
     t = torch.randint(0, 1000, (4,))
