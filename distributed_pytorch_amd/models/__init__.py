@@ -10,6 +10,7 @@ from . import convnext as _cx
 from . import densenet as _dn
 from . import efficientnet as _ef
 from . import googlenet as _gn
+from . import maxvit as _mx
 from . import inception as _in
 from . import mobilenet as _mb
 from . import regnet as _rg
@@ -20,7 +21,7 @@ from . import swin as _sw
 from . import vit as _vt
 
 _REGISTRY: Dict[str, Callable] = {}
-for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in, _cx, _sh, _vt, _sw):
+for _mod in (_rn, _av, _sq, _dn, _mb, _gn, _rg, _ef, _in, _cx, _sh, _vt, _sw, _mx):
     for _name in dir(_mod):
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("_") and callable(_fn) \

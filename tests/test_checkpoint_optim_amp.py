@@ -24,7 +24,7 @@ def test_param_counts_and_torchvision_key_names():
             "efficientnet_v2_s": 21458488, "inception_v3": 23834568, "convnext_tiny": 28589128,
             "shufflenet_v2_x0_5": 1366792, "shufflenet_v2_x1_0": 2278604, "shufflenet_v2_x1_5": 3503624,
             "shufflenet_v2_x2_0": 7393996, "vit_b_16": 86567656, "vit_b_32": 88224232, "swin_t": 28288354,
-            "swin_s": 49606258, "swin_v2_t": 28351570, "swin_v2_b": 87930848}
+            "swin_s": 49606258, "swin_v2_t": 28351570, "swin_v2_b": 87930848, "maxvit_t": 30919624}
     for arch, n in want.items():
         m = models.create_model(arch)
         assert sum(p.numel() for p in m.parameters()) == n, arch

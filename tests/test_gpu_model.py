@@ -29,7 +29,8 @@ def _run(model, x, t):
                                            ("efficientnet_v2_s", 64, 4e-3), ("inception_v3", 171, 6e-3), ("convnext_tiny", 64, 4e-3),
                                            ("shufflenet_v2_x0_5", 96, 4e-3), ("shufflenet_v2_x1_0", 96, 4e-3),
                                            ("shufflenet_v2_x2_0", 64, 4e-3),
-                                           ("vit_b_32", 224, 6e-3), ("swin_t", 64, 6e-3), ("swin_v2_t", 64, 6e-3)])
+                                           ("vit_b_32", 224, 6e-3), ("swin_t", 64, 6e-3), ("swin_v2_t", 64, 6e-3),
+                                           ("maxvit_t", 224, 6e-3)])
 def test_fp32_model_matches_cpu_reference(arch, size, tol):
     from distributed_pytorch_amd import amp, models
 
@@ -269,7 +270,8 @@ def test_lazy_residual_gradient_equals_materialised(arch):
 
 
 @pytest.mark.parametrize("arch", ["regnet_y_128gf", "efficientnet_b7", "convnext_large", "densenet201", "resnext101_64x4d",
-                                  "vgg19_bn", "wide_resnet101_2", "regnet_x_32gf"])
+                                  "vgg19_bn", "wide_resnet101_2", "regnet_x_32gf", "vit_h_14", "vit_l_16", "swin_b",
+                                  "swin_v2_b", "shufflenet_v2_x1_5"])
 def test_largest_zoo_members_take_a_bf16_training_step(arch):
     """The widest / deepest member of each family (7392-channel BatchNorms, 644 M parameters, 2560-wide depthwise
     convolutions ...) runs one AMP O2 step and an eval forward: kernel limits are sized for the whole registry."""

@@ -11,7 +11,7 @@ FAMILIES = [("resnet18", 64), ("resnext50_32x4d", 64), ("alexnet", 96), ("vgg11_
             ("densenet121", 64), ("mobilenet_v2", 64), ("mobilenet_v3_small", 64), ("mnasnet0_5", 64), ("googlenet", 64),
             ("inception_v3", 107), ("regnet_x_400mf", 64), ("regnet_y_400mf", 64), ("efficientnet_b0", 64),
             ("efficientnet_v2_s", 64), ("convnext_tiny", 64), ("shufflenet_v2_x1_0", 64),
-            ("swin_t", 64), ("swin_v2_t", 64)]
+            ("swin_t", 64), ("swin_v2_t", 64), ("maxvit_t", 224)]
 
 
 @pytest.mark.parametrize("arch,size", FAMILIES)
@@ -32,10 +32,10 @@ def test_family_trains_one_step_on_cpu(arch, size):
 
 def test_registry_is_the_arch_choice_list():
     names = models.list_models()
-    assert len(names) == 79 and names == sorted(names)
+    assert len(names) == 80 and names == sorted(names)
     for fam in ("resnet50", "vgg16_bn", "densenet201", "mobilenet_v3_large", "efficientnet_b7", "efficientnet_v2_l",
                 "regnet_y_128gf", "convnext_large", "inception_v3", "googlenet", "mnasnet1_3", "squeezenet1_0",
-                "wide_resnet101_2", "resnext101_64x4d"):
+                "wide_resnet101_2", "resnext101_64x4d", "shufflenet_v2_x2_0", "vit_h_14", "swin_v2_b", "maxvit_t"):
         assert fam in names, fam
     with pytest.raises(KeyError):
         models.create_model("not_a_model")
