@@ -338,6 +338,20 @@ PYBIND11_MODULE(_C, m) {
   m.def("transpose_ktc", [](uintptr_t w, uintptr_t wt, int K, int T, int C, int in_dtype, int out_dtype, uintptr_t s) {
     transpose_ktc_launch(ptr<const void>(w), ptr<void>(wt), K, T, C, in_dtype, out_dtype, st(s));
   });
+  m.def("se_mlp_fwd", [](uintptr_t p, uintptr_t w1, uintptr_t b1, uintptr_t w2, uintptr_t b2, uintptr_t z1, uintptr_t h,
+                         uintptr_t z2, uintptr_t s_, int N, int C, int S, int act, int gate, uintptr_t s) {
+    se_mlp_fwd_launch(ptr<const float>(p), ptr<const float>(w1), ptr<const float>(b1), ptr<const float>(w2),
+                      ptr<const float>(b2), ptr<float>(z1), ptr<float>(h), ptr<float>(z2), ptr<float>(s_), N, C, S, act,
+                      gate, st(s));
+  });
+  m.def("se_mlp_bwd", [](uintptr_t ds, uintptr_t s_, uintptr_t z2, uintptr_t z1, uintptr_t p, uintptr_t h, uintptr_t w1,
+                         uintptr_t w2t, uintptr_t dz2, uintptr_t dz1, uintptr_t dp, uintptr_t dw1, uintptr_t db1,
+                         uintptr_t dw2, uintptr_t db2, int N, int C, int S, int act, int gate, float inv_hw, uintptr_t s) {
+    se_mlp_bwd_launch(ptr<const float>(ds), ptr<const float>(s_), ptr<const float>(z2), ptr<const float>(z1),
+                      ptr<const float>(p), ptr<const float>(h), ptr<const float>(w1), ptr<const float>(w2t),
+                      ptr<float>(dz2), ptr<float>(dz1), ptr<float>(dp), ptr<float>(dw1), ptr<float>(db1), ptr<float>(dw2),
+                      ptr<float>(db2), N, C, S, act, gate, inv_hw, st(s));
+  });
   m.def("attn_max_tokens", &attn_max_tokens);
   m.def("window_partition", [](uintptr_t src, uintptr_t dst, int reverse, int B, int H, int W, int C, int wh, int ww, int nh,
                                int nw, int sh, int sw, int grid_mode, int dtype, uintptr_t s) {

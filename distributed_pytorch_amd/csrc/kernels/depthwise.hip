@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
                                                       FastDiv div_w, FastDiv div_h) {
   constexpr int VEC = 16 / (int)sizeof(T);
   __shared__ float wl[kDwMaxTaps][kDwSlab * VEC];
-  __shared__ float red[2][256][VEC + 1];
+  __shared__ float red[3][256][VEC + 1];      // shifted sum, shifted sum of squares, shift (+ pixel count in slot VEC)
   const int chunks = g.C / VEC;
   const int taps = g.KH * g.KW;
   const int cl = threadIdx.x % CSL, pl = threadIdx.x / CSL, PXL = 256 / CSL;
@@ -155,31 +155,32 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const T* __restrict__ in, 
     o.store(out + (long)pix * g.C + ch * VEC);
   }
   if (!BWD && stats != nullptr) {
-    // per thread (sum, M2 about the thread's mean, pixels); the pixel lanes are merged in double (Chan)
+    // per thread: sums of (v - k_t), (v - k_t)^2 and its shift k_t; the pixel lanes are re-based on the shift of
+    // lane 0 (a sample as well, so every term stays at the scale of the spread) and added in fp32
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      red[0][threadIdx.x][j] = s1[j] + npx * kk[j];
-      red[1][threadIdx.x][j] = npx > 0.f ? fmaxf(s2[j] - s1[j] * s1[j] / npx, 0.f) : 0.f;
+      red[0][threadIdx.x][j] = s1[j];
+      red[1][threadIdx.x][j] = s2[j];
+      red[2][threadIdx.x][j] = kk[j];
     }
     red[0][threadIdx.x][VEC] = npx;
     __syncthreads();
     if (pl == 0 && active) {
-      double N = 0.0;
-      for (int p = 0; p < PXL; ++p) N += (double)red[0][p * CSL + cl][VEC];
+      float N = 0.f;
+      for (int p = 0; p < PXL; ++p) N += red[0][p * CSL + cl][VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        double S = 0.0, Q = 0.0;
+        const float K = red[2][cl][j];          // lane 0 always has a pixel when the block has any
+        float S = 0.f, Q = 0.f;
         for (int p = 0; p < PXL; ++p) {
-          const double n = (double)red[0][p * CSL + cl][VEC];
-          if (n > 0.0) {
-            const double a = (double)red[0][p * CSL + cl][j];
-            S += a;
-            Q += (double)red[1][p * CSL + cl][j] + a * a / n;
-          }
+          const int t = p * CSL + cl;
+          const float n = red[0][t][VEC], a = red[0][t][j], d = red[2][t][j] - K;
+          S += a + n * d;
+          Q += red[1][t][j] + 2.f * d * a + n * d * d;
         }
-        const double m2 = N > 0.0 ? Q - S * S / N : 0.0;
-        stats[((size_t)blockIdx.x * 2 + 0) * g.C + ch * VEC + j] = (float)S;
-        stats[((size_t)blockIdx.x * 2 + 1) * g.C + ch * VEC + j] = (float)(m2 > 0.0 ? m2 : 0.0);
+        const float m2 = N > 0.f ? Q - S * S / N : 0.f;
+        stats[((size_t)blockIdx.x * 2 + 0) * g.C + ch * VEC + j] = S + N * K;
+        stats[((size_t)blockIdx.x * 2 + 1) * g.C + ch * VEC + j] = fmaxf(m2, 0.f);
       }
       if (blockIdx.y == 0 && cl == 0) stats[(size_t)gridDim.x * 2 * g.C + blockIdx.x] = (float)N;
     }

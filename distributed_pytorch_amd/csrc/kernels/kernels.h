@@ -256,6 +256,16 @@ void attn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
                      const float* bias, int nbias, const float* scale, void* dqkv, float* dbias, int nsplit, int B, int H,
                      int S, int D, int dtype, hipStream_t s);
 
+// ------------------------------------------------------------------------------ se_mlp.hip
+// squeeze-excitation MLP on pooled [N][C] fp32 rows: s = gate(W2 act(W1 p + b1) + b2); act 0 ReLU / 1 SiLU, gate 0 sigmoid /
+// 1 hard-sigmoid.  W1 [S][C], W2 [C][S], w2t = W2^T [S][C].  Backward: per-sample gradients + (dw1 != nullptr) parameter
+// gradients summed over the batch in a fixed order.
+void se_mlp_fwd_launch(const float* p, const float* w1, const float* b1, const float* w2, const float* b2, float* z1,
+                       float* h, float* z2, float* s, int N, int C, int S, int act, int gate, hipStream_t st);
+void se_mlp_bwd_launch(const float* ds, const float* s, const float* z2, const float* z1, const float* p, const float* h,
+                       const float* w1, const float* w2t, float* dz2, float* dz1, float* dp, float* dw1, float* db1,
+                       float* dw2, float* db2, int N, int C, int S, int act, int gate, float inv_hw, hipStream_t st);
+
 // ------------------------------------------------------------------------------ optim.hip
 struct SgdTensor {   // one entry per parameter tensor (device table)
   float* p;          // fp32 master / parameter

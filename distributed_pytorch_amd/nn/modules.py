@@ -178,10 +178,8 @@ class SqueezeExcitation(nn.Module):
 
     On the GPU the whole block is one autograd node (``hip_ops._SEBlockFn``): the activation-sized work -- the H*W
     mean, the gate multiply, the backward reduction of ``dy * x`` and ``dx = dy * s + d(mean) / HW`` in one pass -- runs
-    in HIP kernels; the excitation MLP is two ``[N, C] x [C, S]`` fp32
-    products on a tensor 1/(H*W) the size of the activation and goes to the BLAS library through ``torch.addmm``
-    (squeeze widths such as 12 or 26 do not fill an MFMA tile, and at N x C elements the layer is launch latency,
-    not math)."""
+    in HIP kernels, and the excitation MLP (two ``[N, C] x [C, S]`` fp32 products, S = 4 .. a few hundred) is three
+    launches of ``csrc/kernels/se_mlp.hip`` (forward, per-sample backward, parameter gradients)."""
 
     def __init__(self, input_channels: int, squeeze_channels: int, activation: str = "relu",
                  scale_activation: str = "sigmoid"):

@@ -1845,8 +1845,9 @@ class _SEBlockFn(torch.autograd.Function):
     As separate nodes autograd hands ``x`` two gradients -- ``dy * s`` from the gate multiply and the broadcast
     ``d(mean) / HW`` from the pooling -- writes both and adds them (4 activation-sized reads, 3 writes).  Here backward
     first reduces ``ds = sum_hw dy * x`` (2 reads), runs the excitation MLP's backward on ``[N, C]`` tensors, then
-    writes ``dx = dy * s + d(mean) / HW`` in one pass (1 read, 1 write).  The MLP itself (``[N, C] x [C, S]``, fp32)
-    goes to the BLAS library; its parameter gradients are delivered to the gradient sinks like every kernel's."""
+    writes ``dx = dy * s + d(mean) / HW`` in one pass (1 read, 1 write).  The MLP is three launches in total
+    (``csrc/kernels/se_mlp.hip``: forward, per-sample backward, parameter gradients summed over the batch in a fixed
+    order); its parameter gradients are delivered to the gradient sinks like every kernel's."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act, gate):
@@ -1854,52 +1855,59 @@ class _SEBlockFn(torch.autograd.Function):
         NB, H, W, Cc = x.shape
         S = w1.shape[0]
         st = _stream()
-        pooled = torch.empty((NB, 1, 1, Cc), dtype=x.dtype, device=x.device)
+        dev = x.device
+        pooled = torch.empty((NB, 1, 1, Cc), dtype=x.dtype, device=dev)
         C().avgpool_fwd(x.data_ptr(), pooled.data_ptr(), NB, H, W, Cc, 1, 1, _dt(x), st)
         p = pooled.view(NB, Cc).float()
-        W1, W2 = w1.detach().reshape(S, Cc).float(), w2.detach().reshape(Cc, S).float()
-        z1 = torch.addmm(b1.detach().float(), p, W1.t())
-        h = torch.relu(z1) if act == "relu" else torch.nn.functional.silu(z1)
-        z2 = torch.addmm(b2.detach().float(), h, W2.t())
-        s = (torch.sigmoid(z2) if gate == "sigmoid" else torch.nn.functional.hardsigmoid(z2)).contiguous()
+        W1 = w1.detach().reshape(S, Cc).float().contiguous()
+        W2 = w2.detach().reshape(Cc, S).float().contiguous()
+        B1, B2 = b1.detach().float().contiguous(), b2.detach().float().contiguous()
+        buf = torch.empty((2, NB, S), dtype=torch.float32, device=dev)        # z1, h
+        z2 = torch.empty((NB, Cc), dtype=torch.float32, device=dev)
+        s = torch.empty((NB, Cc), dtype=torch.float32, device=dev)
+        ia, ig = (0 if act == "relu" else 1), (0 if gate == "sigmoid" else 1)
+        C().se_mlp_fwd(p.data_ptr(), W1.data_ptr(), B1.data_ptr(), W2.data_ptr(), B2.data_ptr(), buf[0].data_ptr(),
+                       buf[1].data_ptr(), z2.data_ptr(), s.data_ptr(), NB, Cc, S, ia, ig, st)
         y = torch.empty_like(x)
         C().se_scale_fwd(x.data_ptr(), s.data_ptr(), y.data_ptr(), NB, H * W, Cc, _dt(x), st)
-        ctx.save_for_backward(x, s, p, z1, h, z2, w1, w2)
+        ctx.save_for_backward(x, s, p, buf, z2, w1, w2)
         ctx.refs = (b1, b2)
-        ctx.cfg = (act, gate)
+        ctx.cfg = (ia, ig)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, s, p, z1, h, z2, w1, w2 = ctx.saved_tensors
+        x, s, p, buf, z2, w1, w2 = ctx.saved_tensors
         b1, b2 = ctx.refs
-        act, gate = ctx.cfg
+        ia, ig = ctx.cfg
         dy = dy if dy.is_contiguous() else dy.contiguous()
         NB, H, W, Cc = x.shape
         S = w1.shape[0]
         st = _stream()
-        ds = torch.empty((NB, Cc), dtype=torch.float32, device=x.device)
+        dev = x.device
+        ds = torch.empty((NB, Cc), dtype=torch.float32, device=dev)
         C().se_scale_bwd(dy.data_ptr(), x.data_ptr(), s.data_ptr(), 0, ds.data_ptr(), NB, H * W, Cc, _dt(dy), st)
-        if gate == "sigmoid":
-            dz2 = ds * s * (1.0 - s)
-        else:
-            dz2 = ds * ((z2 > -3.0) & (z2 < 3.0)).float() * (1.0 / 6.0)
-        W1, W2 = w1.detach().reshape(S, Cc).float(), w2.detach().reshape(Cc, S).float()
-        dh = dz2 @ W2
-        if act == "relu":
-            dz1 = dh * (z1 > 0).float()
-        else:
-            sg = torch.sigmoid(z1)
-            dz1 = dh * (sg * (1.0 + z1 * (1.0 - sg)))
-        dp = (dz1 @ W1).mul_(1.0 / (H * W)).contiguous()
+        W1 = w1.detach().reshape(S, Cc).float().contiguous()
+        W2t = w2.detach().reshape(Cc, S).float().t().contiguous()
+        dz2 = torch.empty((NB, Cc), dtype=torch.float32, device=dev)
+        dz1 = torch.empty((NB, S), dtype=torch.float32, device=dev)
+        dp = torch.empty((NB, Cc), dtype=torch.float32, device=dev)
+        want_w = any(ctx.needs_input_grad[1:5])
+        gw = torch.empty(2 * S * Cc + S + Cc, dtype=torch.float32, device=dev) if want_w else None
+        o1, o2, o3 = S * Cc, 2 * S * Cc, 2 * S * Cc + S
+        C().se_mlp_bwd(ds.data_ptr(), s.data_ptr(), z2.data_ptr(), buf[0].data_ptr(), p.data_ptr(), buf[1].data_ptr(),
+                       W1.data_ptr(), W2t.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dp.data_ptr(),
+                       gw.data_ptr() if want_w else 0, gw[o2:].data_ptr() if want_w else 0,
+                       gw[o1:].data_ptr() if want_w else 0, gw[o3:].data_ptr() if want_w else 0,
+                       NB, Cc, S, ia, ig, 1.0 / (H * W), st)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             C().se_scale_fwd(dy.data_ptr(), s.data_ptr(), dx.data_ptr(), NB, H * W, Cc, _dt(dy), st, dp.data_ptr())
-        dw1 = _deliver(w1, (dz1.t() @ p).reshape(w1.shape).to(w1.dtype)) if ctx.needs_input_grad[1] else None
-        db1 = _deliver(b1, dz1.sum(0).to(b1.dtype)) if ctx.needs_input_grad[2] else None
-        dw2 = _deliver(w2, (dz2.t() @ h).reshape(w2.shape).to(w2.dtype)) if ctx.needs_input_grad[3] else None
-        db2 = _deliver(b2, dz2.sum(0).to(b2.dtype)) if ctx.needs_input_grad[4] else None
+        dw1 = _deliver(w1, gw[:o1].reshape(w1.shape).to(w1.dtype)) if ctx.needs_input_grad[1] else None
+        db1 = _deliver(b1, gw[o2:o3].to(b1.dtype)) if ctx.needs_input_grad[2] else None
+        dw2 = _deliver(w2, gw[o1:o2].reshape(w2.shape).to(w2.dtype)) if ctx.needs_input_grad[3] else None
+        db2 = _deliver(b2, gw[o3:].to(b2.dtype)) if ctx.needs_input_grad[4] else None
         return dx, dw1, db1, dw2, db2, None, None
 
 
