@@ -112,10 +112,11 @@ struct AttnArgs {
 constexpr int kAttnMaxDB = 4;      // D <= 128
 
 // ------------------------------------------------------------------------------------------------ forward / dQ
-// BWD = false: O and log-sum-exp.  BWD = true: dQ (same loop + the dP product).  Workgroup = 2 waves = 64 queries of one
-// (b, h); K and V (all S tokens) are staged in LDS once.
-template <typename T, bool BWD>
-__global__ __launch_bounds__(128) void attn_q_kernel(const AttnArgs a) {
+// BWD = false: O and log-sum-exp.  BWD = true: dQ (same loop + the dP product).  Workgroup = NW waves = 32 * NW queries of
+// one (b, h); K and V (all S tokens) are staged in LDS once per workgroup (NW = 4 for S > 64: half the staging traffic
+// and twice the waves per LDS byte; NW = 2 for single-window problems, where 4 waves would idle).
+template <typename T, bool BWD, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -128,10 +129,10 @@ __global__ __launch_bounds__(128) void attn_q_kernel(const AttnArgs a) {
   unsigned char* sv = smem + SP * LD;
   const long row_ld = 3l * H * D;
   const T* qkv = reinterpret_cast<const T*>(a.qkv) + (long)b * S * row_ld + (long)h * D;
-  stage_rows<T>(sk, LD, qkv + (long)H * D, row_ld, 0, SP, S, D, DP, tid, 128);
-  stage_rows<T>(sv, LD, qkv + 2l * H * D, row_ld, 0, SP, S, D, DP, tid, 128);
+  stage_rows<T>(sk, LD, qkv + (long)H * D, row_ld, 0, SP, S, D, DP, tid, 64 * NW);
+  stage_rows<T>(sv, LD, qkv + 2l * H * D, row_ld, 0, SP, S, D, DP, tid, 64 * NW);
 
-  const int q = blockIdx.x * 64 + wave * 32 + l31;       // this lane's query row
+  const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;       // this lane's query row
   const bool qok = q < S;
   // Q (and dO) fragments straight from global memory: row q, 8 elements at 16*ks + 8*lh
   uint4 qf[2 * kAttnMaxDB], gf[2 * kAttnMaxDB];
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(128) void attn_q_kernel(const AttnArgs a) {
 // Workgroup = 2 waves = 64 keys of head h; it walks batch entries b = split, split + nsplit, ...  Q and dO of the
 // current (b, h) are staged in LDS (all S tokens), the wave's own K / V rows are read as fragments from global memory.
 // DBIAS (S <= 64: one workgroup covers every key): dS accumulates in registers over the strip of batch entries.
-template <typename T, bool DBIAS>
-__global__ __launch_bounds__(128) void attn_kv_kernel(const AttnArgs a) {
+template <typename T, bool DBIAS, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(128) void attn_kv_kernel(const AttnArgs a) {
   float* s_lse = reinterpret_cast<float*>(smem + 2 * SP * LD);
   float* s_delta = s_lse + SP;
   const long row_ld = 3l * H * D;
-  const int key = blockIdx.x * 64 + wave * 32 + l31;     // this lane's key row
+  const int key = blockIdx.x * (32 * NW) + wave * 32 + l31;     // this lane's key row
   const bool kok = key < S;
   const float scale = a.scale[h];
 
@@ -300,9 +301,9 @@ __global__ __launch_bounds__(128) void attn_kv_kernel(const AttnArgs a) {
     const T* qkv = reinterpret_cast<const T*>(a.qkv) + (long)b * S * row_ld + (long)h * D;
     const T* dout = reinterpret_cast<const T*>(a.dout) + (long)b * S * H * D + (long)h * D;
     __syncthreads();                       // previous batch entry fully consumed
-    stage_rows<T>(sq, LD, qkv, row_ld, 0, SP, S, D, DP, tid, 128);
-    stage_rows<T>(sg, LD, dout, (long)H * D, 0, SP, S, D, DP, tid, 128);
-    for (int i = tid; i < SP; i += 128) {
+    stage_rows<T>(sq, LD, qkv, row_ld, 0, SP, S, D, DP, tid, 64 * NW);
+    stage_rows<T>(sg, LD, dout, (long)H * D, 0, SP, S, D, DP, tid, 64 * NW);
+    for (int i = tid; i < SP; i += 64 * NW) {
       s_lse[i] = i < S ? a.lse[((long)b * H + h) * S + i] : 0.f;
       s_delta[i] = i < S ? a.delta[((long)b * H + h) * S + i] : 0.f;
     }
@@ -620,14 +621,17 @@ void attn_fwd_launch(const void* qkv, void* out, float* lse, const float* bias, 
   a.qkv = qkv; a.out = out; a.lse = lse; a.bias = bias; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale;
   a.B = B; a.H = H; a.S = S; a.D = D;
   const int lds = lds_bytes(S, D, false);
-  dim3 grid(ceil_div(S, 64), B * H);
+  const int nw = S > 64 ? 4 : 2;
+  dim3 grid(ceil_div(S, 32 * nw), B * H);
+#define DPA_ATTN_FWD(T, NW)                                                                  \
+  set_lds(attn_q_kernel<T, false, NW>, lds);                                                 \
+  hipLaunchKernelGGL((attn_q_kernel<T, false, NW>), grid, dim3(64 * NW), lds, s, a);
   if (dtype == kBF16) {
-    set_lds(attn_q_kernel<bf16_t, false>, lds);
-    hipLaunchKernelGGL((attn_q_kernel<bf16_t, false>), grid, dim3(128), lds, s, a);
+    if (nw == 4) { DPA_ATTN_FWD(bf16_t, 4) } else { DPA_ATTN_FWD(bf16_t, 2) }
   } else {
-    set_lds(attn_q_kernel<f16_t, false>, lds);
-    hipLaunchKernelGGL((attn_q_kernel<f16_t, false>), grid, dim3(128), lds, s, a);
+    if (nw == 4) { DPA_ATTN_FWD(f16_t, 4) } else { DPA_ATTN_FWD(f16_t, 2) }
   }
+#undef DPA_ATTN_FWD
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -651,20 +655,25 @@ void attn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
   const long rows = (long)B * S;
   const int dgrid = ceil_div(rows * H, 256);
   const int lds_q = lds_bytes(S, D, false), lds_kv = lds_bytes(S, D, true);
-  dim3 gq(ceil_div(S, 64), B * H), gkv(ceil_div(S, 64), a.nsplit * H);
-#define DPA_ATTN_BWD(T)                                                                                              \
+  const int nw = S > 64 ? 4 : 2;
+  dim3 gq(ceil_div(S, 32 * nw), B * H), gkv(ceil_div(S, 32 * nw), a.nsplit * H);
+#define DPA_ATTN_BWD(T, NW)                                                                                          \
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(dgrid), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, rows, H, \
                      S, D);                                                                                          \
-  set_lds(attn_q_kernel<T, true>, lds_q);                                                                            \
-  hipLaunchKernelGGL((attn_q_kernel<T, true>), gq, dim3(128), lds_q, s, a);                                          \
+  set_lds(attn_q_kernel<T, true, NW>, lds_q);                                                                        \
+  hipLaunchKernelGGL((attn_q_kernel<T, true, NW>), gq, dim3(64 * NW), lds_q, s, a);                                  \
   if (dbias != nullptr) {                                                                                            \
-    set_lds(attn_kv_kernel<T, true>, lds_kv);                                                                        \
-    hipLaunchKernelGGL((attn_kv_kernel<T, true>), gkv, dim3(128), lds_kv, s, a);                                     \
+    set_lds(attn_kv_kernel<T, true, 2>, lds_kv);                                                                     \
+    hipLaunchKernelGGL((attn_kv_kernel<T, true, 2>), gkv, dim3(128), lds_kv, s, a);                                  \
   } else {                                                                                                           \
-    set_lds(attn_kv_kernel<T, false>, lds_kv);                                                                       \
-    hipLaunchKernelGGL((attn_kv_kernel<T, false>), gkv, dim3(128), lds_kv, s, a);                                    \
+    set_lds(attn_kv_kernel<T, false, NW>, lds_kv);                                                                   \
+    hipLaunchKernelGGL((attn_kv_kernel<T, false, NW>), gkv, dim3(64 * NW), lds_kv, s, a);                            \
   }
-  if (dtype == kBF16) { DPA_ATTN_BWD(bf16_t) } else { DPA_ATTN_BWD(f16_t) }
+  if (dtype == kBF16) {
+    if (nw == 4) { DPA_ATTN_BWD(bf16_t, 4) } else { DPA_ATTN_BWD(bf16_t, 2) }
+  } else {
+    if (nw == 4) { DPA_ATTN_BWD(f16_t, 4) } else { DPA_ATTN_BWD(f16_t, 2) }
+  }
 #undef DPA_ATTN_BWD
   DPA_CHECK_HIP(hipGetLastError());
 }

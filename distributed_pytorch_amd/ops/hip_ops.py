@@ -1558,19 +1558,15 @@ class _QKNormFn(torch.autograd.Function):
             dy = dy.to(x.dtype)
         tokens = x.numel() // x.shape[-1]
         dx = torch.empty_like(x)
-        part = torch.empty((tokens, H), dtype=torch.float32, device=x.device)
+        rows4 = _round_up(tokens, 4)
+        part = torch.empty((rows4, H), dtype=torch.float32, device=x.device)
+        if rows4 != tokens:
+            part[tokens:].zero_()
         C().qk_normalize(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), m.data_ptr(), inv.data_ptr(), part.data_ptr(), tokens,
                          H, D, 1, _dt(x), _stream())
-        dm = _colsum_f32(part).reshape(mshape).to(mdtype)
+        # d mult[h] = sum over tokens: the column reducer wants 16-byte rows, so four tokens form one row of 4 * H columns
+        dm = _colsum(part.view(rows4 // 4, 4 * H)).view(4, H).sum(0).reshape(mshape).to(mdtype)
         return (dx if in_dtype == dx.dtype else dx.to(in_dtype)), dm, None
-
-
-def _colsum_f32(part: torch.Tensor) -> torch.Tensor:
-    """Column sums of a small fp32 [rows, n] matrix in a fixed order (slab fold: rows are the slabs)."""
-    rows, n = part.shape
-    out = torch.empty(n, dtype=torch.float32, device=part.device)
-    C().slab_reduce(part.data_ptr(), rows, n, out.data_ptr(), 0, 0.0, _stream())
-    return out
 
 
 def qk_normalize(qkv, mult, num_heads):
