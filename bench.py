@@ -22,6 +22,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -117,6 +118,19 @@ def run(args) -> None:
 
     ddp = world > 1 or args.force_ddp
     backend = None
+    # A rendezvous / communicator build that never returns (a rank that died before joining, a wedged collective) must
+    # end the job with a message instead of hanging the launcher: hard exit after DPA_BENCH_INIT_TIMEOUT_S.
+    init_done = threading.Event()
+    if ddp:
+        limit = float(os.environ.get("DPA_BENCH_INIT_TIMEOUT_S", "600"))
+
+        def _init_watchdog():
+            if not init_done.wait(limit):
+                print("bench.py: rank %d: process-group / model set-up did not finish within %.0f s -- aborting"
+                      % (rank, limit), file=sys.stderr, flush=True)
+                os._exit(3)
+
+        threading.Thread(target=_init_watchdog, daemon=True).start()
     if ddp:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -197,6 +211,7 @@ def run(args) -> None:
     for _ in range(args.warmup):
         loss = step()
     fence()
+    init_done.set()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()

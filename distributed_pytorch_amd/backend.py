@@ -54,3 +54,31 @@ def stream_handle() -> int:
 def host_only() -> bool:
     """True when the run should use the CPU reference backend."""
     return os.environ.get("DPA_FORCE_CPU", "0") == "1" or not torch.cuda.is_available()
+
+
+# ---------------------------------------------------------------------------------------------- HIP stream budget
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 on the target boxes, HIP's default) in
+# creation order; streams beyond that share a queue with an earlier one and then run IN ORDER with it.  Two round-1
+# findings follow from that map (profiles/r1_notes.md, profiles/r2_notes.md): the input copy stream must be created
+# first or it serialises with the compute stream (-4 % under DDP), and a high-priority communication stream that
+# exchanged events with the default stream deadlocked once it shared a queue with it.  The framework therefore owns a
+# fixed, small set of streams -- default (compute), input copy, communication, optional weight-gradient side stream --
+# registers each here when it is created, and warns when the set no longer fits the hardware queues.
+_streams = []
+
+
+def register_stream(name: str) -> None:
+    import os
+    import warnings
+
+    if name in _streams:
+        return
+    _streams.append(name)
+    budget = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    if len(_streams) + 1 > budget:          # + the default stream
+        warnings.warn("HIP streams %s + default exceed GPU_MAX_HW_QUEUES=%d: streams now share hardware queues and run "
+                      "in order with each other (copy / communication overlap is lost)" % (_streams, budget))
+
+
+def streams() -> list:
+    return ["default"] + list(_streams)

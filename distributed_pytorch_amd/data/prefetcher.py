@@ -37,6 +37,9 @@ def copy_stream(device: torch.device) -> "torch.cuda.Stream":
         with torch.cuda.stream(s):
             torch.empty(1, device=device).zero_()     # touch it: the hardware queue is bound on first use
         _copy_streams[key] = s
+        from .. import backend as _backend
+
+        _backend.register_stream("copy")
     return s
 
 

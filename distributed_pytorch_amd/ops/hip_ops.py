@@ -421,6 +421,7 @@ def side_stream(device) -> "torch.cuda.Stream":
     if s is None:
         s = torch.cuda.Stream(device)
         _side_streams[device.index] = s
+        backend.register_stream("wgrad-side")
     return s
 
 

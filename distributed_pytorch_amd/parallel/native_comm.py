@@ -58,6 +58,7 @@ class NativeComm:
         self._p2p = None                # PeerAllReduce, False (unavailable) or None (not set up yet)
         self.p2p_calls = 0
         _shared[0] = self
+        backend.register_stream("comm")           # the communicator's own HIP stream (csrc/comm/comm.cpp)
 
     # ------------------------------------------------------------------ construction
     @classmethod

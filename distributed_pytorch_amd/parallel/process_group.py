@@ -182,6 +182,17 @@ class NativeProcessGroup:
         if use_gpu:
             from .native_comm import NativeComm
 
+            # pre-flight: ncclCommInitRank blocks until EVERY rank calls it, so a rank that cannot even load RCCL (or
+            # sees no device) must be known before anyone enters it
+            pre = ""
+            try:
+                ext.rccl_version()
+                torch.cuda.current_device()
+            except Exception as exc:  # noqa: BLE001
+                pre = "rank %d: %r" % (self.rank, exc)
+            pre_errs = [e.decode() for e in self.host_comm._exchange(pre.encode()) if e]
+            if pre_errs:
+                raise RuntimeError("native RCCL communicator could not be built: " + "; ".join(pre_errs))
             if self.rank == 0:
                 self.store.set("rccl_unique_id", bytes(ext.rccl_unique_id()))
             uid = self.store.get("rccl_unique_id")

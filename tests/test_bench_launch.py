@@ -34,6 +34,26 @@ def test_bench_self_launches_two_ranks_on_cpu():
     assert j["steps"] == 3 and j["warmup"] == 2 and j["value"] > 0 and j["final_loss"] is not None
 
 
+def test_bench_under_torchrun_exactly_as_the_driver_launches_it():
+    """``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...``: ranks come from the environment, MASTER_PORT belongs to torchrun's agent store (ours takes an
+    ephemeral port published through it), rank 0 prints the one JSON line."""
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(launch.free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu", "--arch", "resnet18",
+                        "--image-size", "32", "--num-classes", "10", "--batch-size", "4", "--steps", "3", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["config"]["ranks"] == 2 and j["config"]["parallelism"] == "dp2" and j["steps"] == 3
+    assert j["config"]["comm"]["process_group"] == "native" and j["config"]["comm"]["reducer"] == "c++"
+
+
 def test_bench_fails_fast_when_the_node_has_too_few_devices():
     r = _bench("--gpus", "2", "--device", "cpu", env={"DPA_NPROC_PER_NODE": "1"}, timeout=120)
     assert r.returncode == 2 and "--gpus 2 requested but this node has 1" in r.stderr
