@@ -66,9 +66,11 @@ PYBIND11_MODULE(_C, m) {
         py::arg("a_scale") = 0, py::arg("a_shift") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
   m.attr("IGEMM_AXF") = (int)kIgemmAxf;
+  m.attr("IGEMM_DENSE1") = (int)kIgemmDense1;
   m.def("igemm_axf_ok", &igemm_axf_ok);
   m.attr("IGEMM_ROW3") = (int)kIgemmRow3;
   m.def("igemm_set_row3", &igemm_set_row3);
+  m.def("igemm_set_lean", &igemm_set_lean);
   m.def("igemm_set_nt_store", &igemm_set_nt_store);
   m.def("set_nt_min_bytes", &set_nt_min_bytes);
   m.def("set_nt_mask", &set_nt_mask);

@@ -1,0 +1,474 @@
+// Lean MFMA GEMM for the single-tap problems of the implicit-GEMM interface: 1x1 convolutions without padding
+// (forward, stride 1 or s) and their stride-1 data gradients, Linear layers seen as a 1x1 "image".
+//
+//     C[m][n] = sum_c A[pix(m)][c] * B[n][c]          16-bit in == out, fp32 accumulate
+//
+// Why a second kernel next to igemm.hip: on these shapes the reduction is short (Cred = 64 .. 2048, i.e. 1 .. 32
+// K tiles of 128 bytes) and the general kernel is bound by VALU / SALU issue, not by MFMA or memory -- rocprofv3
+// counters on 14x14 256->1024 at batch 1024 (profiles/r2/pmc_1x1_256_1024.md): 1,073 VALU + 494 SALU instructions
+// per wave and tile against 64 MFMAs, MFMA busy 20 %, 2.2 TB/s.  Four fifths of those instructions sit outside the
+// K loop: tap bookkeeping, 64-bit address arithmetic, bias / ReLU / scatter / tail selects of the epilogue.  This
+// kernel carries none of that:
+//   * one gather offset per staged row, computed once; the K loop advances two scalar base pointers, every
+//     LDS address is a loop-invariant register plus an immediate (the loop is unrolled over both stages);
+//   * no padding masks (every output pixel reads an in-range input pixel; rows past M are clamped on load and
+//     dropped at the store; N is a multiple of the tile width);
+//   * the epilogue is specialised at compile time for what the launch needs: BatchNorm statistics (STATS), the
+//     fused accumulate of a second gradient with its ReLU mask (RACC), the fused BatchNorm-backward reduction
+//     (BNB) -- nothing else is compiled in -- and it requests the extra operands of RACC / BNB half a tile ahead.
+// The accumulator layout, the LDS transposition of the output tile, the Chan-partial statistics slab and the
+// [tiles_m][2][N] + [tiles_m] slab format are those of igemm.hip (igemm_stats_rows() agrees: 128-row tiles).
+//
+// Replaces what cuDNN / cuBLAS ran for the 1x1 convolutions and Linear layers of `model(images)` /
+// `loss.backward()` in the reference (nd_imagenet.py:291,302) -- SURVEY.md N-K1, N-K2, N-K10.
+#include "../common.h"
+#include "kernels.h"
+#include <stdexcept>
+#include <type_traits>
+
+namespace dpa {
+
+namespace {
+
+// a 16-byte register value as a native vector: copies of HIP's uint4 STRUCT between two memories become memcpy
+// calls that the optimiser does not turn into registers (the staging arrays then live in scratch memory)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct LeanMma;
+template <> struct LeanMma<bf16_t> {
+  static __device__ __forceinline__ void run(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    bf16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+};
+template <> struct LeanMma<f16_t> {
+  static __device__ __forceinline__ void run(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    f16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+  }
+};
+
+int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 force 128-byte K tiles
+
+// BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
+// 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
+template <typename T, int BN, int BKB, int MINB, bool STATS, bool RACC, bool BNB, bool STRIDED>
+__global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  constexpr int BM = 128;
+  constexpr int VEC = 8;
+  constexpr int BK = BKB / 2;
+  constexpr int CPR = BKB / 16;                 // 16-byte chunks per staged row
+  constexpr int LDR = BKB + 16;                 // LDS row pitch of a stage (conflict-free b128 fragment reads)
+  constexpr int RPI = 256 / CPR;                // rows staged per pass of the workgroup
+  constexpr int A_IT = BM / RPI, B_IT = BN / RPI;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int STAGE = (BM + BN) * LDR;
+  static_assert(A_IT >= 1 && B_IT >= 1 && NI >= 1, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const uint32_t tiles_n = (uint32_t)p.N / BN;
+  const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = (int)(lid / tiles_n), nt = (int)(lid - (uint32_t)mt * tiles_n);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- global offsets of the rows this thread stages: fixed for the whole kernel -----------------------------
+  const int ch = tid % CPR, r0 = tid / CPR;
+  auto pixel = [&](uint32_t m) __attribute__((always_inline)) -> uint32_t {     // gathered pixel index of output row m
+    if constexpr (!STRIDED) {
+      return m;
+    } else {
+      const uint32_t n = fdiv(m, p.div_ohow);
+      const uint32_t rem = m - n * p.div_ohow.d;
+      const uint32_t oy = fdiv(rem, p.div_ow);
+      const uint32_t ox = rem - oy * p.div_ow.d;
+      return (n * (uint32_t)p.IH + oy * (uint32_t)p.SY) * (uint32_t)p.IW + ox * (uint32_t)p.SX;
+    }
+  };
+  const uint32_t pix0 = pixel((uint32_t)m0);                         // uniform
+  const char* __restrict__ Ag = reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T);
+  const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)n0 * p.ldb * sizeof(T);
+  uint32_t aoff[A_IT], boff[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    uint32_t m = (uint32_t)(m0 + r0 + i * RPI);
+    m = m < (uint32_t)p.M ? m : (uint32_t)p.M - 1u;                  // rows past M: any valid row, never stored
+    aoff[i] = ((pixel(m) - pix0) * (uint32_t)p.lda + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i)
+    boff[i] = ((uint32_t)(r0 + i * RPI) * (uint32_t)p.ldb + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
+
+  // ---- LDS addresses (loop invariant) ---------------------------------------------------------------------
+  unsigned char* const wr_a = smem + r0 * LDR + ch * 16;                       // + i * RPI * LDR
+  unsigned char* const wr_b = smem + BM * LDR + r0 * LDR + ch * 16;
+  const unsigned char* const rd_x = smem + (wm * WTM + l31) * LDR + lh * 16;   // + b * 32 * LDR + ks * 32
+  const unsigned char* const rd_w = smem + BM * LDR + (wn * WTN + l31) * LDR + lh * 16;
+
+  f32x16_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  u32x4_t ra[A_IT], rb[B_IT];
+  auto load_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(Ag + aoff[i]);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const u32x4_t*>(Bg + boff[i]);
+    Ag += BKB;
+    Bg += BKB;
+  };
+  auto store_tile = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_a + stage * STAGE + i * RPI * LDR) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_b + stage * STAGE + i * RPI * LDR) = rb[i];
+  };
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < BKB / 32; ++ks) {
+      u32x4_t wf[NI], xf[MI];
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+        wf[a] = *reinterpret_cast<const u32x4_t*>(rd_w + stage * STAGE + a * 32 * LDR + ks * 32);
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+        xf[b] = *reinterpret_cast<const u32x4_t*>(rd_x + stage * STAGE + b * 32 * LDR + ks * 32);
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) LeanMma<T>::run(acc[a][b], wf[a], xf[b]);
+    }
+  };
+
+  const int nk = p.Cred / BK;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  // (the lambdas above are force-inlined: an out-of-line call would put the staging registers in scratch memory)
+  // two K tiles per trip so that the stage index is a compile-time constant in every LDS address
+  int kt = 0;
+  for (; kt + 2 <= nk; kt += 2) {
+    load_tile();                      // tile kt + 1 (exists)
+    compute(0);
+    store_tile(1);
+    __syncthreads();
+    const bool more = kt + 2 < nk;
+    if (more) load_tile();
+    compute(1);
+    if (more) store_tile(0);
+    __syncthreads();
+  }
+  if (kt < nk) {                      // odd tile count: the last tile sits in stage 0
+    compute(0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte global stores ---------------------------
+  // acc[a][b][r]: channel = wn*WTN + a*32 + (r&3) + 8*(r>>2) + 4*lh, pixel = wm*WTM + b*32 + l31
+  constexpr int LDE = BN * 2 + 16;
+  constexpr int CE = BN / VEC;                  // 16-byte chunks per output row
+  constexpr int RPE = 256 / CE;                 // output rows per pass
+  constexpr int E_IT = BM / RPE;
+  constexpr int EH = E_IT / 2;                  // the rows are processed as two halves (see prefetch below)
+  static_assert(E_IT % 2 == 0, "two halves");
+  unsigned char* const se = smem;
+
+  const int ce = tid % CE, er0 = tid / CE;
+  // 32-bit offsets from the tile's first output row (a tile spans 128 rows of ldc elements)
+  const size_t cbase = ((size_t)m0 * p.ldc + (size_t)n0) * sizeof(T);
+  char* const Cg = reinterpret_cast<char*>(p.C) + cbase;
+  const uint32_t coff0 = ((uint32_t)er0 * (uint32_t)p.ldc + (uint32_t)(ce * VEC)) * (uint32_t)sizeof(T);
+  const uint32_t cstep = (uint32_t)RPE * (uint32_t)p.ldc * (uint32_t)sizeof(T);
+  const int rows = min(BM, p.M - m0);           // uniform
+
+  // Operands the epilogue streams besides the tile itself: R (fused accumulate: the second gradient of a tensor
+  // with two consumers, with the ReLU bit mask it still has to pass) and the BatchNorm input / ReLU bit mask of the
+  // fused BN-backward reduction.  On these launches the epilogue moves 2-4x the bytes of the GEMM operands, so it
+  // is written like a streaming kernel: every 16-byte row piece of a half tile is requested up front -- the first
+  // half before the accumulators go through LDS, the second before the first is consumed -- instead of one
+  // dependent load per row.
+  struct Pre {
+    u32x4_t r[EH], x[EH];
+    uint32_t rbits[EH], xbits[EH];
+  };
+  const int bn_mode = BNB ? p.bn_relu : 0;      // 0 no ReLU, 2 mask recomputed from the BN input, 3 bit mask
+  const char* const Rg = reinterpret_cast<const char*>(p.R) + cbase;
+  const char* const Xg = reinterpret_cast<const char*>(p.bn_x) + cbase;
+  const uint8_t* const rmask = RACC ? p.r_mask : nullptr;
+  const uint8_t* const xmask = (BNB && bn_mode == 3) ? reinterpret_cast<const uint8_t*>(p.bn_z) : nullptr;
+  auto prefetch = [&](int half, Pre& q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < EH; ++i) {
+      const int it = half * EH + i;
+      const bool ok = er0 + it * RPE < rows;
+      const uint32_t off = ok ? coff0 + (uint32_t)it * cstep : (uint32_t)(ce * 16);   // row 0 always exists
+      if constexpr (RACC) {
+        q.r[i] = *reinterpret_cast<const u32x4_t*>(Rg + off);
+        q.rbits[i] = rmask != nullptr ? rmask[(cbase + off) >> 4] : 0xffu;
+      }
+      if constexpr (BNB) {
+        q.x[i] = *reinterpret_cast<const u32x4_t*>(Xg + off);
+        q.xbits[i] = xmask != nullptr ? xmask[(cbase + off) >> 4] : 0xffu;
+      }
+    }
+  };
+  Pre q0, q1;
+  if constexpr (RACC || BNB) prefetch(0, q0);
+
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        T o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = from_float<T>(acc[a][b][4 * g + j]);
+        uint2 w;
+        __builtin_memcpy(&w, o, 8);
+        *reinterpret_cast<uint2*>(se + (wm * WTM + b * 32 + l31) * LDE + (wn * WTN + a * 32 + 8 * g + 4 * lh) * 2) = w;
+      }
+  // LDS-only barrier: __syncthreads() would also wait for the prefetch (vmcnt(0))
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if constexpr (RACC || BNB) prefetch(1, q1);
+
+  float s1[VEC], s2[VEC], kshift[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = kshift[j] = 0.f;
+  if constexpr (STATS) {
+    // Chan partials accumulated around the tile's first row (a sample: |v - k| ~ std), see igemm.hip
+    Vec16<T> k0;
+    k0.load(se + ce * 16);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) kshift[j] = k0.get(j);
+  }
+  float bmu[VEC], bis[VEC], bsc[VEC], bsh[VEC];
+  if constexpr (BNB) {
+    const float* cf = p.bn_coef + n0 + ce * VEC;          // [4][N]: mean, invstd, scale, shift
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      bmu[j] = cf[j];
+      bis[j] = cf[p.N + j];
+      bsc[j] = bn_mode == 2 ? cf[2 * p.N + j] : 0.f;
+      bsh[j] = bn_mode == 2 ? cf[3 * p.N + j] : 0.f;
+    }
+  }
+  const bool nt_store = p.flags & kIgemmNtStore;
+  auto process = [&](int half, const Pre& q, auto mode_c) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+    for (int i = 0; i < EH; ++i) {
+      const int it = half * EH + i;
+      const int row = er0 + it * RPE;
+      if (row >= rows) continue;
+      Vec16<T> v;
+      v.load(se + row * LDE + ce * 16);
+      if constexpr (RACC) {
+        Vec16<T> r;
+        r.raw = make_uint4(q.r[i].x, q.r[i].y, q.r[i].z, q.r[i].w);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (((q.rbits[i] >> j) & 1u) ? r.get(j) : 0.f));
+      }
+      char* dst = Cg + (coff0 + (uint32_t)it * cstep);
+      if (nt_store) v.store_nt(dst);
+      else v.store(dst);
+      if constexpr (STATS) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float f = v.get(j) - kshift[j];
+          s1[j] += f;
+          s2[j] += f * f;
+        }
+      }
+      if constexpr (BNB) {
+        // v holds the values as stored (rounded to T): exactly what BatchNorm backward will read back
+        Vec16<T> xb;
+        xb.raw = make_uint4(q.x[i].x, q.x[i].y, q.x[i].z, q.x[i].w);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float d = v.get(j);
+          const float xv = xb.get(j);
+          if (MODE == 3 && !((q.xbits[i] >> j) & 1u)) d = 0.f;
+          if (MODE == 2 && !(to_float(from_float<T>(bsc[j] * xv + bsh[j])) > 0.f)) d = 0.f;
+          s1[j] += d;
+          s2[j] += d * ((xv - bmu[j]) * bis[j]);
+        }
+      }
+    }
+  };
+  if (bn_mode == 3) {
+    process(0, q0, std::integral_constant<int, 3>());
+    process(1, q1, std::integral_constant<int, 3>());
+  } else if (bn_mode == 2) {
+    process(0, q0, std::integral_constant<int, 2>());
+    process(1, q1, std::integral_constant<int, 2>());
+  } else {
+    process(0, q0, std::integral_constant<int, 0>());
+    process(1, q1, std::integral_constant<int, 0>());
+  }
+  if constexpr (STATS || BNB) {
+    // threads sharing a chunk column: tid = ce (mod CE): reduce inside the wave, then over waves
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+      for (int o = 32; o >= CE; o >>= 1) {
+        s1[j] += __shfl_xor(s1[j], o, 64);
+        s2[j] += __shfl_xor(s2[j], o, 64);
+      }
+    }
+    // LDS-only barrier: __syncthreads() would first drain the tile's global stores (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][BN] + shifts [BN]
+    if (lane < CE) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        red[(wave * 2 + 0) * BN + ce * VEC + j] = s1[j];
+        red[(wave * 2 + 1) * BN + ce * VEC + j] = s2[j];
+        if (STATS && wave == 0) red[8 * BN + ce * VEC + j] = kshift[j];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int sld = p.stats_ld;
+    if constexpr (BNB) {
+      // BatchNorm-backward partials of this tile: (sum dz_m, sum dz_m * xhat)
+      for (int c = tid; c < 2 * BN; c += 256) {
+        const int which = c / BN, col = c - which * BN;
+        const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
+                        red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
+        p.stats[((size_t)mt * 2 + which) * sld + n0 + col] = s;
+      }
+    } else {
+      const float nt_rows = (float)rows;
+      if (tid < BN) {
+        const int col = tid;
+        const float a = red[0 * BN + col] + red[2 * BN + col] + red[4 * BN + col] + red[6 * BN + col];
+        const float b = red[1 * BN + col] + red[3 * BN + col] + red[5 * BN + col] + red[7 * BN + col];
+        const float k = red[8 * BN + col];
+        p.stats[((size_t)mt * 2 + 0) * sld + n0 + col] = a + nt_rows * k;
+        p.stats[((size_t)mt * 2 + 1) * sld + n0 + col] = fmaxf(b - a * a / nt_rows, 0.f);
+      }
+      // rows of this part, behind the slab: [tiles_m][2][stats_ld] floats, then [tiles_m] counts
+      if (tid == 0 && n0 == 0) {
+        const uint32_t tiles_m = gridDim.x / tiles_n;
+        p.stats[(size_t)tiles_m * 2 * sld + mt] = nt_rows;
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int BKB, int MINB, bool STATS, bool RACC, bool BNB, bool STRIDED>
+void launch_lean(const IgemmParams& p, hipStream_t stream) {
+  constexpr int LDR = BKB + 16;
+  constexpr int stage_bytes = (128 + BN) * LDR;
+  constexpr int epi_bytes = 128 * (BN * 2 + 16);
+  constexpr int red_bytes = 9 * BN * 4;
+  constexpr int max_lds = 2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes;
+  int lds = (p.Cred * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
+  if (lds < epi_bytes) lds = epi_bytes;
+  if (lds < red_bytes) lds = red_bytes;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, STATS, RACC, BNB, STRIDED>;
+  static bool attr_done = false;
+  if (!attr_done && max_lds > 64 * 1024) {
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    attr_done = true;
+  }
+  const long tiles = (long)ceil_div(p.M, 128) * (p.N / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
+}
+
+template <typename T, int BN, int BKB, int MINB>
+void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
+  const bool bnb = p.flags & kIgemmBnBwd;
+  const bool stats = p.stats != nullptr && !bnb, racc = p.R != nullptr;
+  if (strided) {                       // strided gathers: forward only (statistics or nothing)
+    if (stats) launch_lean<T, BN, BKB, MINB, true, false, false, true>(p, stream);
+    else launch_lean<T, BN, BKB, MINB, false, false, false, true>(p, stream);
+  } else if (bnb) {
+    if (racc) launch_lean<T, BN, BKB, MINB, false, true, true, false>(p, stream);
+    else launch_lean<T, BN, BKB, MINB, false, false, true, false>(p, stream);
+  } else if (stats) {
+    launch_lean<T, BN, BKB, MINB, true, false, false, false>(p, stream);
+  } else if (racc) {
+    launch_lean<T, BN, BKB, MINB, false, true, false, false>(p, stream);
+  } else {
+    launch_lean<T, BN, BKB, MINB, false, false, false, false>(p, stream);
+  }
+}
+
+template <typename T>
+void launch_lean_tiles(const IgemmParams& p, bool strided, hipStream_t stream) {
+  const bool wide = p.N % 128 == 0;
+  const long tiles = (long)ceil_div(p.M, 128) * (p.N / (wide ? 128 : 64));
+  // 128-byte K tiles (half the barriers) for long reductions and launches that barely fill the chip, as in
+  // igemm.hip's choose_cfg(); 64-byte K tiles (more workgroups per CU) otherwise
+  bool k128 = p.Cred % 64 == 0 && ((long)p.Cred * 2 >= 4096 || tiles <= 512);
+  if (g_lean_mode == 1) k128 = false;
+  if (g_lean_mode == 2) k128 = p.Cred % 64 == 0;
+  if (wide) {
+    if (k128) launch_lean_epi<T, 128, 128, 2>(p, strided, stream);
+    else launch_lean_epi<T, 128, 64, 3>(p, strided, stream);
+  } else {
+    if (k128) launch_lean_epi<T, 64, 128, 3>(p, strided, stream);
+    else launch_lean_epi<T, 64, 64, 4>(p, strided, stream);
+  }
+}
+
+}  // namespace
+
+void igemm_set_lean(int mode) { g_lean_mode = mode; }
+
+// Takes the launch when the problem is one the lean kernel covers; false = the caller runs the general kernel.
+bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream) {
+  if (g_lean_mode == 0) return false;
+  if (dtype != out_dtype || (dtype != kBF16 && dtype != kF16)) return false;
+  if (!(p.flags & kIgemmDense1) || p.ntaps != 1) return false;
+  if (p.flags & (kIgemmRelu | kIgemmScatter | kIgemmAxf)) return false;
+  if (p.bias != nullptr || p.groups > 1) return false;
+  const bool bnb = p.flags & kIgemmBnBwd;
+  if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;
+  // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
+  // from the full BN output (1) stays with the general kernel
+  if (bnb && (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || p.ldc != p.N ||
+              !(p.bn_relu == 0 || p.bn_relu == 2 || (p.bn_relu == 3 && p.bn_z != nullptr))))
+    return false;
+  if (p.M <= 0 || p.N % 64 || p.Cred % 32 || p.lda % 8 || p.ldb % 8 || p.ldc % 8) return false;
+  const long ohow = p.div_ohow.d, ow = p.div_ow.d, oh = ohow / (ow > 0 ? ow : 1);
+  // every output pixel reads pixel (oy * SY, ox * SX): must exist
+  if ((oh - 1) * p.SY >= p.IH || (ow - 1) * p.SX >= p.IW) return false;
+  const bool strided = !(p.SY == 1 && p.SX == 1 && (long)p.IH * p.IW == ohow && p.IW == ow);
+  if (strided && (p.R != nullptr || bnb)) return false;
+  // 32-bit byte offsets inside one tile: the images 128 output rows can touch, the weight panel, the output rows
+  const double images = 130.0 / (double)(ohow > 0 ? ohow : 1) + 2.0;
+  if (images * p.IH * p.IW * p.lda * 2.0 >= 4294967296.0) return false;
+  if ((double)p.N * p.ldb * 2.0 >= 4294967296.0 || 128.0 * p.ldc * 2.0 >= 4294967296.0) return false;
+  if ((double)p.M * (strided ? (double)p.SY * p.SX : 1.0) >= 2147483648.0) return false;
+  IgemmParams q = p;
+  if (q.stats_ld == 0) q.stats_ld = q.N;
+  if (dtype == kBF16) launch_lean_tiles<bf16_t>(q, strided, stream);
+  else launch_lean_tiles<f16_t>(q, strided, stream);
+  return true;
+}
+
+}  // namespace dpa

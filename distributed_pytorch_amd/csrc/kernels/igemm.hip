@@ -1184,6 +1184,10 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     if (p.N % veco != 0 || p.ldc != p.N)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs dense rows of whole 16-byte chunks");
   }
+  if ((p.flags & kIgemmDense1) && g_force_cfg < 0 && gemm_lean_try(p, dtype, out_dtype, stream)) {
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
   if (dtype == kF32 && out_dtype == kF32) dispatch_tiles<float, float>(p, stream);
   else if (dtype == kBF16 && out_dtype == kBF16) dispatch_tiles<bf16_t, bf16_t>(p, stream);
   else if (dtype == kBF16 && out_dtype == kF32) dispatch_tiles<bf16_t, float>(p, stream);

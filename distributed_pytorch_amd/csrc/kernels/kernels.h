@@ -11,8 +11,11 @@ namespace dpa {
 // kIgemmAxf: A is the RAW input z of a training-mode BatchNorm + ReLU; the kernel applies a = relu(a_scale[c] * z +
 // a_shift[c]) while it stages the A tile (the normalised activation is never written to memory).  16-bit dense
 // problems with 64-byte aligned reduction channels only (igemm_axf_ok).
+// kIgemmDense1: the caller guarantees ONE tap (0, 0, 0) -- a 1x1 convolution without padding or a Linear layer --
+// so every output pixel (oy, ox) reads input pixel (oy * SY, ox * SX): such launches may run the lean GEMM
+// (gemm_lean.hip: no tap bookkeeping, no padding masks).
 enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16,
-                        kIgemmAxf = 32 };
+                        kIgemmAxf = 32, kIgemmDense1 = 64 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -57,6 +60,9 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 void igemm_force_config(int cfg);
 // tuning hook for the filter-row kernel: -1 automatic, 0 never, 1 64-byte K tiles, 2 128-byte K tiles
 void igemm_set_row3(int mode);
+// gemm_lean.hip: takes single-tap 16-bit launches (kIgemmDense1) it covers, false = run the general kernel.
+bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
+void igemm_set_lean(int mode);      // tuning hook: -1 automatic, 0 never, 1 / 2 force 64- / 128-byte K tiles
 void igemm_set_nt_store(int mode);  // streaming (nontemporal) stores of the output tile: 0 by size, 1 always, -1 never
 // tensors of at least this many bytes are streamed with nontemporal loads / stores (negative: never)
 void set_nt_min_bytes(long bytes);

@@ -35,6 +35,7 @@ def C():
         _C.bn_set_reverse(_BN_REVERSE)
         _C.igemm_set_row3(int(os.environ.get("DPA_IGEMM_ROW3", "-1")))   # filter-row kernel: -1 auto, 0 off
         _C.igemm_set_nt_store(int(os.environ.get("DPA_IGEMM_NT", "0")))  # 0: by size, 1: always, -1: never
+        _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
         if "DPA_NT_MASK" in os.environ:          # 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm stores
             _C.set_nt_mask(int(os.environ["DPA_NT_MASK"]))
         if "DPA_NT_MIN_MB" in os.environ:        # streaming threshold (default 32 MB); negative: never
@@ -201,7 +202,12 @@ def _tap_table(device, entries) -> torch.Tensor:
     if t is None:
         t = torch.tensor([v for e in entries for v in e], dtype=torch.int32, device=device)
         _taps[key] = t
+        if tuple(entries) == ((0, 0, 0),):
+            _dense1_tables.add(t.data_ptr())
     return t
+
+
+_dense1_tables = set()      # tap tables holding the single tap (0, 0, 0): 1x1 convolutions without padding, Linear
 
 
 def _fprop_taps(R, S, ph, pw):
@@ -239,6 +245,8 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
     ``row3``: the tap table is sorted into filter rows (dy, dx ascending, three taps per row): stride-1 "same"
     convolutions may use the filter-row kernel (one staged activation tile per three taps)."""
     flags = (C().IGEMM_RELU if relu else 0) | (C().IGEMM_ROW3 if row3 else 0)
+    if ntaps == 1 and taps.data_ptr() in _dense1_tables:
+        flags |= C().IGEMM_DENSE1       # eligible for the lean GEMM (csrc/kernels/gemm_lean.hip)
     a_scale = a_shift = 0
     if axf is not None:                 # coef[4][Cred] of the BatchNorm + ReLU applied while A is staged
         flags |= C().IGEMM_AXF
