@@ -263,10 +263,11 @@ PYBIND11_MODULE(_C, m) {
                         ptr<const float>(istd), dtype, st(s));
   });
   m.def("to_s2d", [](uintptr_t x, uintptr_t y, int NB, int H2, int W2, int nchw, int in_dtype, uintptr_t mean,
-                     uintptr_t inv_std, int out_dtype, uintptr_t s) {
+                     uintptr_t inv_std, int out_dtype, uintptr_t s, int padl, int padr) {
     to_s2d_launch(ptr<const void>(x), ptr<void>(y), NB, H2, W2, nchw, in_dtype, ptr<const float>(mean),
-                  ptr<const float>(inv_std), out_dtype, st(s));
-  });
+                  ptr<const float>(inv_std), out_dtype, st(s), padl, padr);
+  }, py::arg("x"), py::arg("y"), py::arg("NB"), py::arg("H2"), py::arg("W2"), py::arg("nchw"), py::arg("in_dtype"),
+     py::arg("mean"), py::arg("inv_std"), py::arg("out_dtype"), py::arg("s"), py::arg("padl") = 0, py::arg("padr") = 0);
   m.def("nchw_to_nhwc", [](uintptr_t x, uintptr_t y, int NB, int C, int HW, int cpad, int in_dtype, int out_dtype,
                            uintptr_t s) {
     nchw_to_nhwc_launch(ptr<const void>(x), ptr<void>(y), NB, C, HW, cpad, in_dtype, out_dtype, st(s));

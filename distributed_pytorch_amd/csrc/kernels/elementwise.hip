@@ -45,13 +45,17 @@ __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __rest
 // (py*2 + px)*3 + c holds pixel (2Y+py, 2X+px), channels 12..15 are zero.  The stem then is a 4x4 stride-1
 // convolution over 16 channels (K = 256 instead of 7*7*8 = 392 with channel padding) on a tensor half the size.
 // U8: (x - 255*mean_c) / (255*std_c) (the prefetcher's normalisation); otherwise a plain conversion.
+// The output rows may carry `padl` / `padr` zero pixels left / right of the W2 data pixels: with two on the left and
+// (at least) one on the right the four horizontal taps of an output pixel are 64 CONTIGUOUS in-range channels, and
+// the stem runs as a 4-tap x 64-channel problem on the aligned kernels (hip_ops._StemS2DFn).
 template <typename TI, typename TO, bool U8>
 __global__ __launch_bounds__(256) void to_s2d_kernel(const TI* __restrict__ x, TO* __restrict__ y, int NB, int H2, int W2,
                                                      int nchw, const float* __restrict__ mean255,
-                                                     const float* __restrict__ inv_std255) {
+                                                     const float* __restrict__ inv_std255, int padl, int padr) {
   constexpr int VEC = 16 / (int)sizeof(TO);
   constexpr int CH = 16 / VEC;                       // chunks per s2d pixel
-  const long total = (long)NB * H2 * W2 * CH;
+  const int WP = W2 + padl + padr;
+  const long total = (long)NB * H2 * WP * CH;
   const long stride = (long)gridDim.x * blockDim.x;
   const int H = 2 * H2, W = 2 * W2;
   float mu[3] = {0.f, 0.f, 0.f}, is[3] = {1.f, 1.f, 1.f};
@@ -62,15 +66,16 @@ __global__ __launch_bounds__(256) void to_s2d_kernel(const TI* __restrict__ x, T
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int h = (int)(i % CH);
     long pix = i / CH;
-    const int X = (int)(pix % W2); pix /= W2;
+    const int X = (int)(pix % WP) - padl; pix /= WP;
     const int Y = (int)(pix % H2);
     const long n = pix / H2;
+    const bool inside = X >= 0 && X < W2;
     Vec16<TO> o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int ch = h * VEC + j;
       float v = 0.f;
-      if (ch < 12) {
+      if (ch < 12 && inside) {
         const int q = ch / 3, c = ch - q * 3;
         const int iy = 2 * Y + (q >> 1), ix = 2 * X + (q & 1);
         const long src = nchw ? ((n * 3 + c) * H + iy) * W + ix : ((n * H + iy) * W + ix) * 3 + c;
@@ -410,18 +415,18 @@ void normalize_u8_launch(const uint8_t* x, void* y, long npix, int cin, int cout
 }
 
 void to_s2d_launch(const void* x, void* y, int NB, int H2, int W2, int nchw, int in_dtype, const float* mean255,
-                   const float* inv_std255, int out_dtype, hipStream_t s) {
-  const long total = (long)NB * H2 * W2 * (out_dtype == kF32 ? 4 : 2);
+                   const float* inv_std255, int out_dtype, hipStream_t s, int padl, int padr) {
+  const long total = (long)NB * H2 * (W2 + padl + padr) * (out_dtype == kF32 ? 4 : 2);
   if (total <= 0) return;
   if (in_dtype < 0) {      // uint8 source
     if (mean255 == nullptr || inv_std255 == nullptr) throw std::invalid_argument("to_s2d: uint8 input needs mean / std");
     DPA_DISPATCH_DTYPE(out_dtype, hipLaunchKernelGGL((to_s2d_kernel<uint8_t, T, true>), dim3(grid_for(total)), dim3(256),
                                                      0, s, (const uint8_t*)x, (T*)y, NB, H2, W2, nchw, mean255,
-                                                     inv_std255));
+                                                     inv_std255, padl, padr));
   } else {
     DPA_DISPATCH_2(in_dtype, out_dtype,
                    hipLaunchKernelGGL((to_s2d_kernel<TI, TO, false>), dim3(grid_for(total)), dim3(256), 0, s,
-                                      (const TI*)x, (TO*)y, NB, H2, W2, nchw, nullptr, nullptr));
+                                      (const TI*)x, (TO*)y, NB, H2, W2, nchw, nullptr, nullptr, padl, padr));
   }
   DPA_CHECK_HIP(hipGetLastError());
 }

@@ -56,7 +56,7 @@ int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 fo
 
 // BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
-template <typename T, int BN, int BKB, int MINB, bool STATS, bool RACC, bool BNB, bool STRIDED>
+template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BM = 128;
@@ -123,20 +123,22 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  u32x4_t ra[A_IT], rb[B_IT];
-  auto load_tile = [&]() __attribute__((always_inline)) {
+  // PF register sets: PF K tiles are in flight while one is consumed (a K step computes for ~300 cycles, a load
+  // takes 1-2k under load: with one tile in flight every K step pays most of a memory latency)
+  u32x4_t ra[PF][A_IT], rb[PF][B_IT];
+  auto load_tile = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(Ag + aoff[i]);
+    for (int i = 0; i < A_IT; ++i) ra[set][i] = *reinterpret_cast<const u32x4_t*>(Ag + aoff[i]);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const u32x4_t*>(Bg + boff[i]);
+    for (int i = 0; i < B_IT; ++i) rb[set][i] = *reinterpret_cast<const u32x4_t*>(Bg + boff[i]);
     Ag += BKB;
     Bg += BKB;
   };
-  auto store_tile = [&](int stage) __attribute__((always_inline)) {
+  auto store_tile = [&](int set, int stage) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_a + stage * STAGE + i * RPI * LDR) = ra[i];
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_a + stage * STAGE + i * RPI * LDR) = ra[set][i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_b + stage * STAGE + i * RPI * LDR) = rb[i];
+    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_b + stage * STAGE + i * RPI * LDR) = rb[set][i];
   };
   auto compute = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
@@ -155,25 +157,42 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
     }
   };
 
-  const int nk = p.Cred / BK;
-  load_tile();
-  store_tile(0);
-  __syncthreads();
   // (the lambdas above are force-inlined: an out-of-line call would put the staging registers in scratch memory)
-  // two K tiles per trip so that the stage index is a compile-time constant in every LDS address
+  // two K tiles per trip so that stage and register-set indices are compile-time constants
+  const int nk = p.Cred / BK;
   int kt = 0;
-  for (; kt + 2 <= nk; kt += 2) {
-    load_tile();                      // tile kt + 1 (exists)
-    compute(0);
-    store_tile(1);
+  if constexpr (PF == 1) {
+    load_tile(0);
+    store_tile(0, 0);
     __syncthreads();
-    const bool more = kt + 2 < nk;
-    if (more) load_tile();
-    compute(1);
-    if (more) store_tile(0);
+    for (; kt + 2 <= nk; kt += 2) {
+      load_tile(0);                     // tile kt + 1 (exists)
+      compute(0);
+      store_tile(0, 1);
+      __syncthreads();
+      const bool more = kt + 2 < nk;
+      if (more) load_tile(0);
+      compute(1);
+      if (more) store_tile(0, 0);
+      __syncthreads();
+    }
+  } else {
+    load_tile(0);
+    if (nk > 1) load_tile(1);
+    store_tile(0, 0);
     __syncthreads();
+    for (; kt + 2 <= nk; kt += 2) {
+      if (kt + 2 < nk) load_tile(0);    // tile kt + 2 into the set tile kt has just left
+      compute(0);
+      store_tile(1, 1);                 // tile kt + 1: waits for ITS loads only, tile kt + 2 stays in flight
+      __syncthreads();
+      if (kt + 3 < nk) load_tile(1);
+      compute(1);
+      if (kt + 2 < nk) store_tile(0, 0);
+      __syncthreads();
+    }
   }
-  if (kt < nk) {                      // odd tile count: the last tile sits in stage 0
+  if (kt < nk) {                        // odd tile count: the last tile sits in stage 0
     compute(0);
     __syncthreads();
   }
@@ -377,7 +396,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   }
 }
 
-template <typename T, int BN, int BKB, int MINB, bool STATS, bool RACC, bool BNB, bool STRIDED>
+template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
@@ -387,7 +406,7 @@ void launch_lean(const IgemmParams& p, hipStream_t stream) {
   int lds = (p.Cred * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, STATS, RACC, BNB, STRIDED>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -398,22 +417,22 @@ void launch_lean(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, stream, p);
 }
 
-template <typename T, int BN, int BKB, int MINB>
+template <typename T, int BN, int BKB, int MINB, int PF>
 void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   const bool bnb = p.flags & kIgemmBnBwd;
   const bool stats = p.stats != nullptr && !bnb, racc = p.R != nullptr;
   if (strided) {                       // strided gathers: forward only (statistics or nothing)
-    if (stats) launch_lean<T, BN, BKB, MINB, true, false, false, true>(p, stream);
-    else launch_lean<T, BN, BKB, MINB, false, false, false, true>(p, stream);
+    if (stats) launch_lean<T, BN, BKB, MINB, PF, true, false, false, true>(p, stream);
+    else launch_lean<T, BN, BKB, MINB, PF, false, false, false, true>(p, stream);
   } else if (bnb) {
-    if (racc) launch_lean<T, BN, BKB, MINB, false, true, true, false>(p, stream);
-    else launch_lean<T, BN, BKB, MINB, false, false, true, false>(p, stream);
+    if (racc) launch_lean<T, BN, BKB, MINB, PF, false, true, true, false>(p, stream);
+    else launch_lean<T, BN, BKB, MINB, PF, false, false, true, false>(p, stream);
   } else if (stats) {
-    launch_lean<T, BN, BKB, MINB, true, false, false, false>(p, stream);
+    launch_lean<T, BN, BKB, MINB, PF, true, false, false, false>(p, stream);
   } else if (racc) {
-    launch_lean<T, BN, BKB, MINB, false, true, false, false>(p, stream);
+    launch_lean<T, BN, BKB, MINB, PF, false, true, false, false>(p, stream);
   } else {
-    launch_lean<T, BN, BKB, MINB, false, false, false, false>(p, stream);
+    launch_lean<T, BN, BKB, MINB, PF, false, false, false, false>(p, stream);
   }
 }
 
@@ -426,12 +445,14 @@ void launch_lean_tiles(const IgemmParams& p, bool strided, hipStream_t stream) {
   bool k128 = p.Cred % 64 == 0 && ((long)p.Cred * 2 >= 4096 || tiles <= 512);
   if (g_lean_mode == 1) k128 = false;
   if (g_lean_mode == 2) k128 = p.Cred % 64 == 0;
+  // PF = 2 (two K tiles in flight in registers) measured the same as PF = 1 on every ResNet-50 layer
+  // (profiles/r2/lean_gemm_prefetch_depth.txt): the K loop is not what these launches wait for
   if (wide) {
-    if (k128) launch_lean_epi<T, 128, 128, 2>(p, strided, stream);
-    else launch_lean_epi<T, 128, 64, 3>(p, strided, stream);
+    if (k128) launch_lean_epi<T, 128, 128, 2, 1>(p, strided, stream);
+    else launch_lean_epi<T, 128, 64, 3, 1>(p, strided, stream);
   } else {
-    if (k128) launch_lean_epi<T, 64, 128, 3>(p, strided, stream);
-    else launch_lean_epi<T, 64, 64, 4>(p, strided, stream);
+    if (k128) launch_lean_epi<T, 64, 128, 3, 1>(p, strided, stream);
+    else launch_lean_epi<T, 64, 64, 4, 1>(p, strided, stream);
   }
 }
 

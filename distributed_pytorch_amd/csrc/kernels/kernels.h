@@ -190,9 +190,10 @@ void xent_bwd_scale_launch(void* dlogits, long n, int dtype, const float* gout, 
 // ------------------------------------------------------------------------------ elementwise.hip
 void normalize_u8_launch(const uint8_t* x, void* y, long npix, int cin, int cout, int hw, int nchw,
                          const float* mean255, const float* inv_std255, int dtype, hipStream_t s);
-// images -> space-to-depth [N][H/2][W/2][16] (in_dtype < 0: uint8 source, normalised with mean255 / inv_std255)
+// images -> space-to-depth [N][H/2][padl + W/2 + padr][16] (in_dtype < 0: uint8 source, normalised with mean255 /
+// inv_std255); the pad pixels are zero
 void to_s2d_launch(const void* x, void* y, int NB, int H2, int W2, int nchw, int in_dtype, const float* mean255,
-                   const float* inv_std255, int out_dtype, hipStream_t s);
+                   const float* inv_std255, int out_dtype, hipStream_t s, int padl = 0, int padr = 0);
 void nchw_to_nhwc_launch(const void* x, void* y, int NB, int C, int HW, int cpad, int in_dtype,
                          int out_dtype, hipStream_t s);
 void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);

@@ -2162,6 +2162,12 @@ def normalize_u8(x, dtype, pad_c, mean, std, input_layout):
 # ------------------------------------------------------------------------------------------
 _STEM_S2D = os.environ.get("DPA_STEM_S2D", "1") == "1"
 _S2D_TAPS = tuple((ty - 2, tx - 2, ty * 4 + tx) for ty in range(4) for tx in range(4))
+# With the image rows padded by two zero pixels on the left and two on the right (to_s2d does that), the four
+# horizontal taps of an output pixel are 64 contiguous, always in-range channels: the stem becomes a 4-tap x
+# 64-channel problem (128-byte aligned rows) and runs on the aligned implicit-GEMM / weight-gradient kernels instead
+# of the 32-byte generic gather (fprop 1.65 -> ~0.9 ms, wgrad 1.35 -> ~0.8 ms at batch 1024).
+_S2D_PADL, _S2D_PADR = 2, 2
+_S2D_ROW_TAPS = tuple((ty - 2, 0, ty) for ty in range(4))
 _s2d_idx: Dict[int, torch.Tensor] = {}
 
 
@@ -2185,7 +2191,8 @@ def to_s2d(x, dtype, mean, std):
         NB, H, W, _ = x.shape
     else:
         NB, _, H, W = x.shape
-    y = torch.empty((NB, H // 2, W // 2, 16), dtype=dtype, device=x.device)
+    base = torch.empty((NB, H // 2, W // 2 + _S2D_PADL + _S2D_PADR, 16), dtype=dtype, device=x.device)
+    y = base[:, :, _S2D_PADL:_S2D_PADL + W // 2]     # [N, H/2, W/2, 16] view of the zero-padded rows
     if x.dtype == torch.uint8:
         key = (x.device.index, tuple(mean), tuple(std))
         if key not in _norm_consts:
@@ -2193,12 +2200,14 @@ def to_s2d(x, dtype, mean, std):
             s = torch.tensor([1.0 / (v * 255.0) for v in std], dtype=torch.float32, device=x.device)
             _norm_consts[key] = (m, s)
         m, s = _norm_consts[key]
-        C().to_s2d(x.data_ptr(), y.data_ptr(), NB, H // 2, W // 2, 0 if nhwc else 1, -1, m.data_ptr(), s.data_ptr(),
-                   _dt(dtype), _stream())
+        C().to_s2d(x.data_ptr(), base.data_ptr(), NB, H // 2, W // 2, 0 if nhwc else 1, -1, m.data_ptr(), s.data_ptr(),
+                   _dt(dtype), _stream(), _S2D_PADL, _S2D_PADR)
     else:
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             x = x.float()
-        C().to_s2d(x.data_ptr(), y.data_ptr(), NB, H // 2, W // 2, 1, _dt(x), 0, 0, _dt(dtype), _stream())
+        C().to_s2d(x.data_ptr(), base.data_ptr(), NB, H // 2, W // 2, 1, _dt(x), 0, 0, _dt(dtype), _stream(),
+                   _S2D_PADL, _S2D_PADR)
+    y._dpa_s2d_base = base
     y._dpa_s2d = True
     y._dpa_nhwc = True
     return y
@@ -2231,7 +2240,13 @@ def stem_weight_s2d(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 class _StemS2DFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu, want_stats):
-        x = x if x.is_contiguous() else x.contiguous()
+        # `x` from to_s2d() is a view of zero-padded rows (`_dpa_s2d_base`): 4 taps x 64 contiguous channels; any
+        # other [N, H/2, W/2, 16] tensor takes the 16 taps x 16 channels form
+        base = getattr(x, "_dpa_s2d_base", None)
+        padded = base is not None and x.data_ptr() == base.data_ptr() + _S2D_PADL * 16 * x.element_size() \
+            and x.stride() == base.stride()
+        if not padded:
+            x = x if x.is_contiguous() else x.contiguous()
         NB, H2, W2, Cx = x.shape
         K = weight.shape[0]
         if Cx != 16 or tuple(weight.shape[1:]) != (3, 7, 7):
@@ -2239,16 +2254,19 @@ class _StemS2DFn(torch.autograd.Function):
         w2 = stem_weight_s2d(weight, x.dtype)
         M = NB * H2 * W2
         y = torch.empty((NB, H2, W2, K), dtype=x.dtype, device=x.device)
+        src, cred, ntaps, iw = (base, 64, 4, W2 + _S2D_PADL + _S2D_PADR) if padded else (x, 16, 16, W2)
         stats = None
         if want_stats:
-            tiles = C().igemm_stats_rows(M, K, 16, 16, _dt(x), _dt(x))
+            tiles = C().igemm_stats_rows(M, K, cred, ntaps, _dt(x), _dt(x))
             stats = _stats_slab(tiles, K, x.device)
-        taps = _tap_table(x.device, _S2D_TAPS)
+        taps = _tap_table(x.device, _S2D_ROW_TAPS if padded else _S2D_TAPS)
         bias_f = None
         if bias is not None:
             bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
-        _igemm(x, w2, y, bias_f, stats, taps, M, K, 16, 16, 16, 256, K, H2, W2, 1, 1, H2, W2, relu=relu,
+        _igemm(src, w2, y, bias_f, stats, taps, M, K, cred, ntaps, 16, 256, K, H2, iw, 1, 1, H2, W2, relu=relu,
                dtype=x.dtype, out_dtype=x.dtype)
+        ctx.padded = padded
+        ctx.src = src if padded else None
         ctx.cfg = (relu, bias is not None)
         ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -2276,9 +2294,14 @@ class _StemS2DFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             splits, pps = C().wgrad_choose_splits(M, K, 256, _dt(dy))
             slab = torch.empty((splits, K, 256), dtype=torch.float32, device=dy.device)
-            taps = _tap_table(dy.device, _S2D_TAPS)
-            C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, 16, 16, K, 16, H2, W2, 1, 1,
-                      H2, W2, splits, pps, 0, _dt(dy), st)
+            if ctx.padded:
+                taps = _tap_table(dy.device, _S2D_ROW_TAPS)
+                C().wgrad(dy.data_ptr(), ctx.src.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, 64, 4, K, 16, H2,
+                          W2 + _S2D_PADL + _S2D_PADR, 1, 1, H2, W2, splits, pps, 0, _dt(dy), st)
+            else:
+                taps = _tap_table(dy.device, _S2D_TAPS)
+                C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, 16, 16, K, 16, H2, W2,
+                          1, 1, H2, W2, splits, pps, 0, _dt(dy), st)
             full = torch.empty((K, 256), dtype=torch.float32, device=dy.device)
             C().slab_reduce(slab.data_ptr(), splits, K * 256, full.data_ptr(), 0, 0.0, st)
             g = full[:, _s2d_index(dy.device)].view(K, 7, 7, 3).permute(0, 3, 1, 2)
