@@ -50,7 +50,7 @@ def build(verbose: bool = False, force: bool = False, jobs: int = 0) -> str:
     inc = ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I" + CSRC,
            "-I" + os.path.join(ROCM, "include")]
     common = [HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-              "-Wno-unused-result"] + inc
+              "-Wno-unused-result"] + inc + os.environ.get("DPA_BUILD_DEFS", "").split()
     hmt = _headers_mtime()
     todo, objs = [], []
     for src in _sources():

@@ -52,11 +52,12 @@ template <> struct LeanMma<f16_t> {
   }
 };
 
+int g_lean_abl = 0;     // debug ablation of the plain variant (scratch/lean_ablate.py)
 int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 force 128-byte K tiles
 
 // BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
-template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED>
+template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BM = 128;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   // takes 1-2k under load: with one tile in flight every K step pays most of a memory latency)
   u32x4_t ra[PF][A_IT], rb[PF][B_IT];
   auto load_tile = [&](int set) __attribute__((always_inline)) {
+    if (ABL == 3 && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T)) return;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) ra[set][i] = *reinterpret_cast<const u32x4_t*>(Ag + aoff[i]);
 #pragma unroll
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
     for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_b + stage * STAGE + i * RPI * LDR) = rb[set][i];
   };
   auto compute = [&](int stage) __attribute__((always_inline)) {
+    if (ABL == 2) return;
 #pragma unroll
     for (int ks = 0; ks < BKB / 32; ++ks) {
       u32x4_t wf[NI], xf[MI];
@@ -153,7 +156,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 #pragma unroll
       for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < MI; ++b) LeanMma<T>::run(acc[a][b], wf[a], xf[b]);
+        for (int b = 0; b < MI; ++b) {
+          if (ABL == 1) asm volatile("" ::"v"(wf[a]), "v"(xf[b]));
+          else LeanMma<T>::run(acc[a][b], wf[a], xf[b]);
+        }
     }
   };
 
@@ -306,7 +312,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
         for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (((q.rbits[i] >> j) & 1u) ? r.get(j) : 0.f));
       }
       char* dst = Cg + (coff0 + (uint32_t)it * cstep);
-      if (nt_store) v.store_nt(dst);
+      if (ABL == 4) asm volatile("" ::"v"(v.raw.x), "v"(v.raw.y), "v"(v.raw.z), "v"(v.raw.w));
+      else if (nt_store) v.store_nt(dst);
       else v.store(dst);
       if constexpr (STATS) {
 #pragma unroll
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   }
 }
 
-template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED>
+template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
@@ -406,7 +413,7 @@ void launch_lean(const IgemmParams& p, hipStream_t stream) {
   int lds = (p.Cred * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -432,6 +439,17 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   } else if (racc) {
     launch_lean<T, BN, BKB, MINB, PF, false, true, false, false>(p, stream);
   } else {
+#ifdef DPA_LEAN_ABLATE
+    if constexpr (BN == 128 && sizeof(T) == 2) {
+      switch (g_lean_abl) {
+        case 1: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 1>(p, stream); return;
+        case 2: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 2>(p, stream); return;
+        case 3: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 3>(p, stream); return;
+        case 4: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 4>(p, stream); return;
+        default: break;
+      }
+    }
+#endif
     launch_lean<T, BN, BKB, MINB, PF, false, false, false, false>(p, stream);
   }
 }
@@ -459,6 +477,7 @@ void launch_lean_tiles(const IgemmParams& p, bool strided, hipStream_t stream) {
 }  // namespace
 
 void igemm_set_lean(int mode) { g_lean_mode = mode; }
+void igemm_set_lean_ablate(int a) { g_lean_abl = a; }
 
 // Takes the launch when the problem is one the lean kernel covers; false = the caller runs the general kernel.
 bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream) {

@@ -62,7 +62,8 @@ void igemm_force_config(int cfg);
 void igemm_set_row3(int mode);
 // gemm_lean.hip: takes single-tap 16-bit launches (kIgemmDense1) it covers, false = run the general kernel.
 bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
-void igemm_set_lean(int mode);      // tuning hook: -1 automatic, 0 never, 1 / 2 force 64- / 128-byte K tiles
+void igemm_set_lean(int mode);
+void igemm_set_lean_ablate(int a);   // debug builds (-DDPA_LEAN_ABLATE) only: 1 no MFMA, 2 no compute, 3 no loop loads, 4 no store      // tuning hook: -1 automatic, 0 never, 1 / 2 force 64- / 128-byte K tiles
 void igemm_set_nt_store(int mode);  // streaming (nontemporal) stores of the output tile: 0 by size, 1 always, -1 never
 // tensors of at least this many bytes are streamed with nontemporal loads / stores (negative: never)
 void set_nt_min_bytes(long bytes);
