@@ -454,8 +454,12 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   }
 }
 
+
 template <typename T>
 void launch_lean_tiles(const IgemmParams& p, bool strided, hipStream_t stream) {
+  // A 256 x 256 tile (8 waves of 128 x 64, half the staged bytes per MFMA) in this same loop structure measured
+  // +3 .. 15 % on the deep layers and 896 vs 822 TFLOP/s on a 200k x 2048 x 2048 GEMM
+  // (profiles/r2/lean_gemm_256x256_tile.txt): not worth a second set of epilogues; the structure, not the tile, caps it.
   const bool wide = p.N % 128 == 0;
   const long tiles = (long)ceil_div(p.M, 128) * (p.N / (wide ? 128 : 64));
   // 128-byte K tiles (half the barriers) for long reductions and launches that barely fill the chip, as in
