@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   // takes 1-2k under load: with one tile in flight every K step pays most of a memory latency)
   u32x4_t ra[PF][A_IT], rb[PF][B_IT];
   auto load_tile = [&](int set) __attribute__((always_inline)) {
-    if (ABL == 3 && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T)) return;
+    if ((ABL == 3 || ABL >= 5) && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T)) {
+      Ag += BKB;      // (keeps the first-tile test of store_tile exact)
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) ra[set][i] = *reinterpret_cast<const u32x4_t*>(Ag + aoff[i]);
 #pragma unroll
@@ -137,30 +140,37 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
     Bg += BKB;
   };
   auto store_tile = [&](int set, int stage) __attribute__((always_inline)) {
+    if (ABL >= 5 && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T) + BKB) return;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_a + stage * STAGE + i * RPI * LDR) = ra[set][i];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_b + stage * STAGE + i * RPI * LDR) = rb[set][i];
   };
+  // All fragment reads of a K tile are written ahead of its MFMAs; the compiler interleaves them with counted
+  // lgkmcnt waits.  (Measured neutral against read-just-before-use: a pure ds_read + MFMA + barrier loop -- no global
+  // loads, no LDS writes -- runs at ~50 % MFMA utilisation either way, profiles/r2/lean_gemm_ablation.txt.)
   auto compute = [&](int stage) __attribute__((always_inline)) {
     if (ABL == 2) return;
+    constexpr int KS = BKB / 32;
+    u32x4_t wf[KS][NI], xf[KS][MI];
 #pragma unroll
-    for (int ks = 0; ks < BKB / 32; ++ks) {
-      u32x4_t wf[NI], xf[MI];
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int a = 0; a < NI; ++a)
-        wf[a] = *reinterpret_cast<const u32x4_t*>(rd_w + stage * STAGE + a * 32 * LDR + ks * 32);
+        wf[ks][a] = *reinterpret_cast<const u32x4_t*>(rd_w + stage * STAGE + a * 32 * LDR + ks * 32);
 #pragma unroll
       for (int b = 0; b < MI; ++b)
-        xf[b] = *reinterpret_cast<const u32x4_t*>(rd_x + stage * STAGE + b * 32 * LDR + ks * 32);
+        xf[ks][b] = *reinterpret_cast<const u32x4_t*>(rd_x + stage * STAGE + b * 32 * LDR + ks * 32);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int a = 0; a < NI; ++a)
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
-          if (ABL == 1) asm volatile("" ::"v"(wf[a]), "v"(xf[b]));
-          else LeanMma<T>::run(acc[a][b], wf[a], xf[b]);
+          if (ABL == 1) asm volatile("" ::"v"(wf[ks][a]), "v"(xf[ks][b]));
+          else LeanMma<T>::run(acc[a][b], wf[ks][a], xf[ks][b]);
         }
-    }
   };
 
   // (the lambdas above are force-inlined: an out-of-line call would put the staging registers in scratch memory)
@@ -446,6 +456,7 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
         case 2: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 2>(p, stream); return;
         case 3: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 3>(p, stream); return;
         case 4: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 4>(p, stream); return;
+        case 5: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 5>(p, stream); return;
         default: break;
       }
     }
