@@ -109,6 +109,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   const bool relu = p.flags & kIgemmRelu;
   const int ce = tid % CE;
   const int ncol = n0 + ce * VECO;
+  // fused BatchNorm-backward reduction: the extra operands (BN input, BN output or its bit mask) of the first half
+  // of the rows are requested BEFORE the accumulators go through LDS, those of the second half right behind the
+  // barrier: loaded one dependent row at a time these launches ran at half the memory rate (profiles/r2_notes.md)
+  uint4 px[E_IT], pz[E_IT];
+  uint32_t pbits[E_IT];           // bn_relu == 3: bn_z is the BN's bit mask (one byte per 16-byte chunk)
+  auto bnb_request = [&](int first, int last) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < E_IT; ++i) {
+      if (i < first || i >= last) continue;
+      const uint32_t m = m0 + (tid + i * 256) / CE;
+      const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0, no scatter
+      const size_t goff = ok ? ((size_t)m * p.ldc + ncol) * sizeof(TOut) : 0;
+      px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
+      if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);
+      pbits[i] = p.bn_relu == 3 ? reinterpret_cast<const uint8_t*>(p.bn_z)[goff / 16] : 0u;
+    }
+  };
+  constexpr int E_HALF = E_IT > 1 ? E_IT / 2 : 1;
+  if constexpr (BNB) bnb_request(0, E_HALF);
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
 #pragma unroll
@@ -142,7 +161,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       }
     }
   }
-  __syncthreads();
+  // LDS-only barrier: __syncthreads() would also wait for the requests above (vmcnt(0))
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if constexpr (BNB) bnb_request(E_HALF, E_IT);
 
   float s1[VECO], s2[VECO];
 #pragma unroll
@@ -163,12 +186,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     }
   }
   char* __restrict__ Cg = reinterpret_cast<char*>(p.C) + gofs * sizeof(TOut);
-  // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column, and ALL
-  // rows of the extra operands requested at once (inside the store loop each row paid a full memory latency;
-  // the accumulators are dead by now, so the 2 x E_IT vectors cost no occupancy)
+  // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column (the extra operands
+  // of every row were requested above)
   float bmu[VECO], bis[VECO], bsc[VECO], bsh[VECO];
-  uint4 px[E_IT], pz[E_IT];
-  uint32_t pbits[E_IT];           // bn_relu == 3: bn_z is the BN's bit mask (one byte per 16-byte chunk)
   if constexpr (BNB) {
 #pragma unroll
     for (int j = 0; j < VECO; ++j) {
@@ -177,15 +197,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       bis[j] = p.bn_coef[p.N + c];
       bsc[j] = p.bn_coef[2 * p.N + c];
       bsh[j] = p.bn_coef[3 * p.N + c];
-    }
-#pragma unroll
-    for (int i = 0; i < E_IT; ++i) {
-      const uint32_t m = m0 + (tid + i * 256) / CE;
-      const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0, no scatter
-      const size_t goff = ok ? ((size_t)m * p.ldc + ncol) * sizeof(TOut) : 0;
-      px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
-      if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);
-      pbits[i] = p.bn_relu == 3 ? reinterpret_cast<const uint8_t*>(p.bn_z)[goff / 16] : 0u;
     }
   }
 #pragma unroll
