@@ -30,6 +30,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -134,11 +136,25 @@ class Communicator {
       check_nccl(rccl().CommInitRank(&c, world, uid, rank), "ncclCommInitRank");
       comm_.store(c);
     }
-    // Normal priority by default.  A high-priority stream that event-waits on work of torch's default
-    // (null) stream DEADLOCKED on MI355X / ROCm 7.0 runtime with GPU_MAX_HW_QUEUES=4 (both streams stay
-    // busy forever, measured 2026-11: profiles/r1_notes.md); DPA_COMM_PRIORITY=1 opts back in.
+    // Normal priority by default.  Cause of the round-1 deadlock, established in round 2
+    // (profiles/r2/priority_stream_hw_queues.txt): a high-priority stream needs a hardware queue of its own
+    // priority class; with GPU_MAX_HW_QUEUES=4 (the pool's setting, HIP's default) and this job's default, copy
+    // and RCCL streams already on the normal queues it ends up sharing a hardware queue with a stream it
+    // event-waits on, and the cyclic wait compute -> comm -> compute never drains.  The identical run with
+    // GPU_MAX_HW_QUEUES=8 completes (12.2k img/s, forced-DDP ResNet-50).  DPA_COMM_PRIORITY=1 therefore takes
+    // effect only when the process was started with at least 8 hardware queues; otherwise it is refused loudly.
     const char* prio = getenv("DPA_COMM_PRIORITY");
-    if (prio && std::string(prio) == "1") {
+    bool want_prio = prio && std::string(prio) == "1";
+    if (want_prio) {
+      const char* q = getenv("GPU_MAX_HW_QUEUES");
+      const int queues = q ? atoi(q) : 4;
+      if (queues < 8) {
+        fprintf(stderr, "[dpa comm] DPA_COMM_PRIORITY=1 ignored: GPU_MAX_HW_QUEUES=%d < 8 would alias the priority "
+                        "stream onto a queue it waits on (deadlock); using a normal-priority stream\n", queues);
+        want_prio = false;
+      }
+    }
+    if (want_prio) {
       int lo = 0, hi = 0;
       CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
       CHECK_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
