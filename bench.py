@@ -82,7 +82,30 @@ def self_launch(args) -> int:
     return 0
 
 
+_REAL_STDOUT = None
+
+
+def _claim_stdout() -> None:
+    """The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL's version banner at
+    communicator creation: 'RCCL version : ... / Librccl path : ...'), so file descriptor 1 is pointed at stderr for
+    the whole run and the JSON line goes to a private duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line: str) -> None:
+    sys.stdout.flush()
+    data = (line + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def run(args) -> None:
+    _claim_stdout()
     import torch
 
     from distributed_pytorch_amd import amp, launch, models
@@ -238,7 +261,7 @@ def run(args) -> None:
             comm["rccl_version"] = int(_be.require().rccl_version())
         comm["cpu_affinity"] = len(cpus)
     if rank == 0:
-        print(json.dumps({
+        _emit(json.dumps({
             "metric": "images/sec (whole job) %s %s training" % (
                 {"resnet50": "ResNet-50"}.get(args.arch, args.arch), "AMP" if args.dtype != "fp32" else "fp32"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": n_ranks if use_gpu else 0, "steps": args.steps,
@@ -256,7 +279,7 @@ def run(args) -> None:
                        "hip_graph": bool(graphed is not None and graphed.replays > 0),
                        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1) if use_gpu else None,
                        "comm": comm},
-        }), flush=True)
+        }))
     if ddp:
         pg.barrier()
         pg.destroy_process_group()
