@@ -175,44 +175,48 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 
   // (the lambdas above are force-inlined: an out-of-line call would put the staging registers in scratch memory)
   // two K tiles per trip so that stage and register-set indices are compile-time constants
+  auto loop_sync = [&]() __attribute__((always_inline)) {
+    if (ABL != 6) __syncthreads();      // ablation 6: how much of the pure read + MFMA loop is barrier skew
+  };
   const int nk = p.Cred / BK;
   int kt = 0;
   if constexpr (PF == 1) {
     load_tile(0);
     store_tile(0, 0);
-    __syncthreads();
+    loop_sync();
     for (; kt + 2 <= nk; kt += 2) {
       load_tile(0);                     // tile kt + 1 (exists)
       compute(0);
       store_tile(0, 1);
-      __syncthreads();
+      loop_sync();
       const bool more = kt + 2 < nk;
       if (more) load_tile(0);
       compute(1);
       if (more) store_tile(0, 0);
-      __syncthreads();
+      loop_sync();
     }
   } else {
     load_tile(0);
     if (nk > 1) load_tile(1);
     store_tile(0, 0);
-    __syncthreads();
+    loop_sync();
     for (; kt + 2 <= nk; kt += 2) {
       if (kt + 2 < nk) load_tile(0);    // tile kt + 2 into the set tile kt has just left
       compute(0);
       store_tile(1, 1);                 // tile kt + 1: waits for ITS loads only, tile kt + 2 stays in flight
-      __syncthreads();
+      loop_sync();
       if (kt + 3 < nk) load_tile(1);
       compute(1);
       if (kt + 2 < nk) store_tile(0, 0);
-      __syncthreads();
+      loop_sync();
     }
   }
   if (kt < nk) {                        // odd tile count: the last tile sits in stage 0
     compute(0);
-    __syncthreads();
+    loop_sync();
   }
 
+  if (ABL == 6) __syncthreads();
   // ---- epilogue: registers -> LDS tile [pixel][channel] -> 16-byte global stores ---------------------------
   // acc[a][b][r]: channel = wn*WTN + a*32 + (r&3) + 8*(r>>2) + 4*lh, pixel = wm*WTM + b*32 + l31
   constexpr int LDE = BN * 2 + 16;
@@ -457,6 +461,7 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
         case 3: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 3>(p, stream); return;
         case 4: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 4>(p, stream); return;
         case 5: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 5>(p, stream); return;
+        case 6: launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 6>(p, stream); return;
         default: break;
       }
     }
