@@ -57,7 +57,8 @@ int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 fo
 
 // BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
-template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0>
+template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
+          bool BIAS = false>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BM = 128;
@@ -116,13 +117,27 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   const unsigned char* const rd_x = smem + (wm * WTM + l31) * LDR + lh * 16;   // + b * 32 * LDR + ks * 32
   const unsigned char* const rd_w = smem + BM * LDR + (wn * WTN + l31) * LDR + lh * 16;
 
+  // BIAS (Linear layers): the accumulators START at the bias of their channel -- register r of lane half lh is channel
+  // (r&3) + 8*(r>>2) + 4*lh of the 32-block -- so the epilogue has nothing to add (one fp32 rounding, as in the
+  // general kernel; only the order of the fp32 additions differs).
   f32x16_t acc[NI][MI];
 #pragma unroll
-  for (int a = 0; a < NI; ++a)
+  for (int a = 0; a < NI; ++a) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + wn * WTN + a * 32 + 8 * g + 4 * lh);
+        bv[4 * g + 0] = b4.x; bv[4 * g + 1] = b4.y; bv[4 * g + 2] = b4.z; bv[4 * g + 3] = b4.w;
+      }
+    }
 #pragma unroll
     for (int b = 0; b < MI; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = bv[r];
+  }
 
   // PF register sets: PF K tiles are in flight while one is consumed (a K step computes for ~300 cycles, a load
   // takes 1-2k under load: with one tile in flight every K step pays most of a memory latency)
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   };
   Pre q0, q1;
   if constexpr (RACC || BNB) prefetch(0, q0);
+  const bool relu_out = BIAS && (p.flags & kIgemmRelu);
 
 #pragma unroll
   for (int a = 0; a < NI; ++a)
@@ -277,7 +293,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       for (int b = 0; b < MI; ++b) {
         T o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = from_float<T>(acc[a][b][4 * g + j]);
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[a][b][4 * g + j];
+          if (BIAS && relu_out) v = fmaxf(v, 0.f);
+          o[j] = from_float<T>(v);
+        }
         uint2 w;
         __builtin_memcpy(&w, o, 8);
         *reinterpret_cast<uint2*>(se + (wm * WTM + b * 32 + l31) * LDE + (wn * WTN + a * 32 + 8 * g + 4 * lh) * 2) = w;
@@ -417,7 +437,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   }
 }
 
-template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0>
+template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
+          bool BIAS = false>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
@@ -427,7 +448,7 @@ void launch_lean(const IgemmParams& p, hipStream_t stream) {
   int lds = (p.Cred * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -442,6 +463,10 @@ template <typename T, int BN, int BKB, int MINB, int PF>
 void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   const bool bnb = p.flags & kIgemmBnBwd;
   const bool stats = p.stats != nullptr && !bnb, racc = p.R != nullptr;
+  if (p.bias != nullptr) {             // Linear forward (gemm_lean_try admits a bias only on the plain variant)
+    launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true>(p, stream);
+    return;
+  }
   if (strided) {                       // strided gathers: forward only (statistics or nothing)
     if (stats) launch_lean<T, BN, BKB, MINB, PF, true, false, false, true>(p, stream);
     else launch_lean<T, BN, BKB, MINB, PF, false, false, false, true>(p, stream);
@@ -504,9 +529,12 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if (g_lean_mode == 0) return false;
   if (dtype != out_dtype || (dtype != kBF16 && dtype != kF16)) return false;
   if (!(p.flags & kIgemmDense1) || p.ntaps != 1) return false;
-  if (p.flags & (kIgemmRelu | kIgemmScatter | kIgemmAxf)) return false;
-  if (p.bias != nullptr || p.groups > 1) return false;
+  if (p.flags & (kIgemmScatter | kIgemmAxf)) return false;
+  if (p.groups > 1) return false;
   const bool bnb = p.flags & kIgemmBnBwd;
+  // bias (+ ReLU): Linear layers, plain epilogue only
+  if ((p.flags & kIgemmRelu) && p.bias == nullptr) return false;
+  if (p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;
   if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;
   // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
   // from the full BN output (1) stays with the general kernel
@@ -518,7 +546,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   // every output pixel reads pixel (oy * SY, ox * SX): must exist
   if ((oh - 1) * p.SY >= p.IH || (ow - 1) * p.SX >= p.IW) return false;
   const bool strided = !(p.SY == 1 && p.SX == 1 && (long)p.IH * p.IW == ohow && p.IW == ow);
-  if (strided && (p.R != nullptr || bnb)) return false;
+  if (strided && (p.R != nullptr || bnb || p.bias != nullptr)) return false;
   // 32-bit byte offsets inside one tile: the images 128 output rows can touch, the weight panel, the output rows
   const double images = 130.0 / (double)(ohow > 0 ? ohow : 1) + 2.0;
   if (images * p.IH * p.IW * p.lda * 2.0 >= 4294967296.0) return false;

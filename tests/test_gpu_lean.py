@@ -162,3 +162,27 @@ def test_data_gradient_with_fused_bn_backward_reduction(case, with_accum, mode):
     dm = torch.where(keep, d, torch.zeros_like(d))
     ref = torch.stack([dm.sum(0), (dm * ((xf - mean) * invstd)).sum(0)])
     assert_close(res[-1][1].sum(0), ref, torch.float32, "slab vs reference", scale=8)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape", [(300, 512, 1024), (197 * 3, 768, 3072), (64, 64, 64), (130, 3072, 768)])
+def test_linear_with_bias_starts_the_accumulators_at_the_bias(shape, relu):
+    """BIAS variant: same fp32 sum as the general kernel up to the order of the additions, one rounding."""
+    hip_ops, C = _ops()
+    M, K, N = shape
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda")
+    try:
+        C.igemm_set_lean(0)
+        y0 = hip_ops.linear(x, w, b, relu, None, torch.bfloat16)
+        C.igemm_set_lean(-1)
+        y1 = hip_ops.linear(x, w, b, relu, None, torch.bfloat16)
+    finally:
+        C.igemm_set_lean(-1)
+    ref = x.float() @ w.bfloat16().float().t() + b
+    if relu:
+        ref = ref.clamp_min(0)
+    assert_close(y1, ref, torch.bfloat16, "linear + bias")
+    assert_close(y1, y0.float(), torch.bfloat16, "lean vs general kernel", scale=0.5)
