@@ -2242,6 +2242,8 @@ class _StemS2DFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu, want_stats):
         # `x` from to_s2d() is a view of zero-padded rows (`_dpa_s2d_base`): 4 taps x 64 contiguous channels; any
         # other [N, H/2, W/2, 16] tensor takes the 16 taps x 16 channels form
+        _tap_table(x.device, _S2D_TAPS)          # both tables exist after the first (eager) call: a table made
+        _tap_table(x.device, _S2D_ROW_TAPS)      # inside a hipGraph capture would be an illegal host-to-device copy
         base = getattr(x, "_dpa_s2d_base", None)
         padded = base is not None and x.data_ptr() == base.data_ptr() + _S2D_PADL * 16 * x.element_size() \
             and x.stride() == base.stride()

@@ -62,7 +62,15 @@ class GraphedTrainStep:
         return loss, rec
 
     def _capture(self, images, target):
-        self.static_x = images.clone()
+        base = getattr(images, "_dpa_s2d_base", None)
+        if base is not None and images.stride() == base.stride() and images._base is base:
+            # to_s2d() hands out a view of zero-padded rows (the stem reads the padding): keep that layout
+            sbase = base.clone()
+            off = images.storage_offset() - base.storage_offset()
+            self.static_x = sbase.as_strided(images.shape, images.stride(), sbase.storage_offset() + off)
+            self.static_x._dpa_s2d_base = sbase
+        else:
+            self.static_x = images.clone()
         self.static_t = target.clone()
         if getattr(images, "_dpa_nhwc", False):      # the prefetcher's "already normalised NHWC" tag
             self.static_x._dpa_nhwc = True

@@ -188,7 +188,7 @@ def test_syncbn_gpu_path_equals_plain_bn_on_one_rank(act):
         assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2 * float(a.float().abs().max()))
 
 
-@pytest.mark.parametrize("arch", ["resnet18", "mobilenet_v3_small"])
+@pytest.mark.parametrize("arch", ["resnet18", "mobilenet_v3_small", "resnet18:prefetched"])
 def test_hip_graph_step_matches_eager_training(arch):
     """--hip-graph: the captured + replayed step leaves exactly the eager trajectory (same kernels, same order),
     and the learning rate can still change between replays."""
@@ -198,6 +198,9 @@ def test_hip_graph_step_matches_eager_training(arch):
     from distributed_pytorch_amd.optim import FusedSGD
     from distributed_pytorch_amd.utils.graph import GraphedTrainStep
 
+    # ":prefetched": the batches arrive as the prefetcher delivers them (space-to-depth layout on zero-padded rows, a
+    # strided view): the graph's static input has to keep that layout
+    arch, _, feed = arch.partition(":")
     amp.state().reset()
     torch.manual_seed(0)
     # mobilenet_v3_small: squeeze-excitation weights get their gradients through autograd's AccumulateGrad (not a
@@ -219,6 +222,9 @@ def test_hip_graph_step_matches_eager_training(arch):
         for i, (x, t) in enumerate(zip(xs, ts)):
             if i == 5:
                 opt.param_groups[0]["lr"] = 0.01
+            if feed == "prefetched":
+                from distributed_pytorch_amd.ops import functional as F
+                x = F.to_s2d(x, torch.bfloat16)
             loss, _ = stepper(x, t)
             losses.append(float(loss))
         if use_graph:
