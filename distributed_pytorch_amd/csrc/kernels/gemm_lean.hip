@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
     u32x4_t r[EH], x[EH];
     uint32_t rbits[EH], xbits[EH];
   };
-  const int bn_mode = BNB ? p.bn_relu : 0;      // 0 no ReLU, 2 mask recomputed from the BN input, 3 bit mask
+  const int bn_mode = BNB ? (p.bn_relu & 3) : 0;   // 0 no ReLU, 2 mask recomputed from the BN input, 3 bit mask
+  const bool bn_clip = BNB && (p.bn_relu & 4);     // ReLU6: the recomputed mask is 0 < y < 6
   const char* const Rg = reinterpret_cast<const char*>(p.R) + cbase;
   const char* const Xg = reinterpret_cast<const char*>(p.bn_x) + cbase;
   const uint8_t* const rmask = RACC ? p.r_mask : nullptr;
@@ -366,7 +367,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
           float d = v.get(j);
           const float xv = xb.get(j);
           if (MODE == 3 && !((q.xbits[i] >> j) & 1u)) d = 0.f;
-          if (MODE == 2 && !(to_float(from_float<T>(bsc[j] * xv + bsh[j])) > 0.f)) d = 0.f;
+          if (MODE == 2) {
+            const float yv = to_float(from_float<T>(bsc[j] * xv + bsh[j]));
+            if (!(yv > 0.f) || (bn_clip && !(yv < 6.f))) d = 0.f;
+          }
           s1[j] += d;
           s2[j] += d * ((xv - bmu[j]) * bis[j]);
         }
@@ -539,7 +543,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
   // from the full BN output (1) stays with the general kernel
   if (bnb && (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || p.ldc != p.N ||
-              !(p.bn_relu == 0 || p.bn_relu == 2 || (p.bn_relu == 3 && p.bn_z != nullptr))))
+              !(p.bn_relu == 0 || p.bn_relu == 2 || p.bn_relu == 6 || (p.bn_relu == 3 && p.bn_z != nullptr))))
     return false;
   if (p.M <= 0 || p.N % 64 || p.Cred % 32 || p.lda % 8 || p.ldb % 8 || p.ldc % 8) return false;
   const long ohow = p.div_ohow.d, ow = p.div_ow.d, oh = ohow / (ow > 0 ? ow : 1);

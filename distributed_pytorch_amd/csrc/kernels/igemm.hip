@@ -255,7 +255,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
           const float xv = xb.get(j);
           if (p.bn_relu == 1 && !(zb.get(j) > 0.f)) d = 0.f;
           if (p.bn_relu == 3 && !((pbits[i] >> j) & 1u)) d = 0.f;
-          if (p.bn_relu == 2 && !(to_float(from_float<TOut>(bsc[j] * xv + bsh[j])) > 0.f)) d = 0.f;
+          if ((p.bn_relu & 3) == 2) {           // mask recomputed from the BN input; bit 2: ReLU6 (0 < y < 6)
+            const float yv = to_float(from_float<TOut>(bsc[j] * xv + bsh[j]));
+            if (!(yv > 0.f) || ((p.bn_relu & 4) && !(yv < 6.f))) d = 0.f;
+          }
           s1[j] += d;
           s2[j] += d * ((xv - bmu[j]) * bis[j]);
         }

@@ -28,7 +28,8 @@ struct IgemmParams {
   float* stats;        // optional per-channel partial (sum, sum^2) slab [tiles_m][2][N]
   // kIgemmBnBwd (data-gradient launches): the output is the gradient dz of z = [relu](bn(bn_x) [+ res]); the
   // slab then receives the BatchNorm-backward partials (sum dz_m, sum dz_m * xhat) instead, dz_m = dz masked by
-  // the ReLU (bn_relu 0: none, 1: bn_z > 0, 2: scale*bn_x + shift > 0), so BN backward skips its reduce pass.
+  // the ReLU (bn_relu 0: none, 1: bn_z > 0, 2: scale*bn_x + shift > 0, 3: bn_z is a bit mask, 6 = 2 | 4: ReLU6, mask
+  // 0 < scale*bn_x + shift < 6), so BN backward skips its reduce pass.
   const void* bn_x;    // BN input, same rows / ldc as C
   const void* bn_z;    // BN output (bn_relu == 1)
   const float* bn_coef;  // [4][N]: mean, invstd, scale, shift

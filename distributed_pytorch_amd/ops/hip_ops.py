@@ -1082,7 +1082,8 @@ class _BNFn(torch.autograd.Function):
                             and residual.shape == x.shape and residual.dtype == x.dtype
                             and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)))
         ctx.cfg = (relu_mode | clip | (act << 4), residual is not None, group, count)
-        _BNFn.last = None if (clip or act) else _BnSrc(x, coef, relu_mode, mask)
+        # ReLU6 without a residual: the consumer recomputes 0 < scale * x + shift < 6 (mode 2 | 4)
+        _BNFn.last = None if (act or (clip and relu_mode != 2)) else _BnSrc(x, coef, relu_mode | clip, mask)
         return y
 
     @staticmethod

@@ -117,7 +117,7 @@ def test_linear_layer_runs_the_lean_kernel_and_matches():
     assert_close(y1, x.float() @ w.bfloat16().float().t(), torch.bfloat16, "linear")
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("mode", [0, 2, 3, 6])
 @pytest.mark.parametrize("with_accum", [False, True])
 @pytest.mark.parametrize("case", [(4, 14, 256, 1024, 1), (3, 9, 64, 64, 1), (5, 7, 96, 192, 1), (2, 6, 320, 256, 1)])
 def test_data_gradient_with_fused_bn_backward_reduction(case, with_accum, mode):
@@ -131,7 +131,7 @@ def test_data_gradient_with_fused_bn_backward_reduction(case, with_accum, mode):
     w = (torch.randn(Cout, Cin, 1, 1, device="cuda") * Cout ** -0.5).contiguous(memory_format=torch.channels_last)
     bn_x = (torch.randn(NB, H, H, Cin, device="cuda") * 2 + 0.5).to(dtype)
     mean, invstd = torch.randn(Cin, device="cuda") * 0.3 + 0.5, torch.rand(Cin, device="cuda") + 0.5
-    scale, shift = torch.randn(Cin, device="cuda"), torch.randn(Cin, device="cuda") * 0.2
+    scale, shift = torch.randn(Cin, device="cuda") * 3, torch.randn(Cin, device="cuda") * 0.2
     coef = torch.stack([mean, invstd, scale, shift]).contiguous()
     bits = torch.randint(0, 256, (NB * H * H * Cin // 8,), dtype=torch.uint8, device="cuda")
     other = torch.randn(NB, H, H, Cin, device="cuda").to(dtype) if with_accum else None
@@ -155,6 +155,9 @@ def test_data_gradient_with_fused_bn_backward_reduction(case, with_accum, mode):
     xf = bn_x.float().reshape(-1, Cin)
     if mode == 3:
         keep = ((bits.view(-1, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8)) & 1).reshape(-1, Cin).bool()
+    elif mode == 6:                      # ReLU6: 0 < y < 6
+        yv = (scale * xf + shift).to(dtype).float()
+        keep = (yv > 0) & (yv < 6)
     elif mode == 2:
         keep = (scale * xf + shift).to(dtype).float() > 0
     else:
