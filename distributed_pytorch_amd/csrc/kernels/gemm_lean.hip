@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   const char* const Rg = reinterpret_cast<const char*>(p.R) + cbase;
   const char* const Xg = reinterpret_cast<const char*>(p.bn_x) + cbase;
   const uint8_t* const rmask = RACC ? p.r_mask : nullptr;
+  const bool rstr = RACC && (p.flags & kIgemmRStrided);
+  const int lsy = rstr ? __builtin_ctz((unsigned)p.OSY) : 0, lsx = rstr ? __builtin_ctz((unsigned)p.OSX) : 0;
   const uint8_t* const xmask = (BNB && bn_mode == 3) ? reinterpret_cast<const uint8_t*>(p.bn_z) : nullptr;
   auto prefetch = [&](int half, Pre& q) __attribute__((always_inline)) {
 #pragma unroll
@@ -273,8 +275,23 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       const bool ok = er0 + it * RPE < rows;
       const uint32_t off = ok ? coff0 + (uint32_t)it * cstep : (uint32_t)(ce * 16);   // row 0 always exists
       if constexpr (RACC) {
-        q.r[i] = *reinterpret_cast<const u32x4_t*>(Rg + off);
-        q.rbits[i] = rmask != nullptr ? rmask[(cbase + off) >> 4] : 0xffu;
+        if (rstr) {
+          // R is COMPACT: the gradient of a stride-s 1x1 branch on its own (OHF x OWF) grid; output pixel (y, x)
+          // takes row (y / s, x / s) when both are multiples of s and nothing otherwise
+          const uint32_t mm = ok ? (uint32_t)(m0 + er0 + it * RPE) : (uint32_t)m0;
+          const uint32_t n = fdiv(mm, p.div_ohow);
+          const uint32_t rem = mm - n * p.div_ohow.d;
+          const uint32_t y = fdiv(rem, p.div_ow);
+          const uint32_t x = rem - y * p.div_ow.d;
+          const bool hit = ok && !(y & (uint32_t)(p.OSY - 1)) && !(x & (uint32_t)(p.OSX - 1));
+          const size_t cp = hit ? ((size_t)n * p.OHF + (y >> lsy)) * p.OWF + (x >> lsx) : (size_t)0;
+          q.r[i] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.R) +
+                                                     (cp * p.ldc + (size_t)(n0 + ce * VEC)) * sizeof(T));
+          q.rbits[i] = hit ? 0xffu : 0u;
+        } else {
+          q.r[i] = *reinterpret_cast<const u32x4_t*>(Rg + off);
+          q.rbits[i] = rmask != nullptr ? rmask[(cbase + off) >> 4] : 0xffu;
+        }
       }
       if constexpr (BNB) {
         q.x[i] = *reinterpret_cast<const u32x4_t*>(Xg + off);
@@ -530,7 +547,7 @@ void igemm_set_lean_ablate(int a) { g_lean_abl = a; }
 
 // Takes the launch when the problem is one the lean kernel covers; false = the caller runs the general kernel.
 bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream) {
-  if (g_lean_mode == 0) return false;
+  if (g_lean_mode == 0 && !(p.flags & kIgemmRStrided)) return false;    // (a compact accumulate has no other kernel)
   if (dtype != out_dtype || (dtype != kBF16 && dtype != kF16)) return false;
   if (!(p.flags & kIgemmDense1) || p.ntaps != 1) return false;
   if (p.flags & (kIgemmScatter | kIgemmAxf)) return false;
@@ -551,6 +568,12 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if ((oh - 1) * p.SY >= p.IH || (ow - 1) * p.SX >= p.IW) return false;
   const bool strided = !(p.SY == 1 && p.SX == 1 && (long)p.IH * p.IW == ohow && p.IW == ow);
   if (strided && (p.R != nullptr || bnb || p.bias != nullptr)) return false;
+  if (p.flags & kIgemmRStrided) {      // compact R of a strided 1x1 branch (see the kernel's prefetch)
+    auto pow2 = [](int v) { return v >= 1 && (v & (v - 1)) == 0; };
+    if (p.R == nullptr || p.r_mask != nullptr || strided || !pow2(p.OSY) || !pow2(p.OSX) ||
+        p.OHF != (oh + p.OSY - 1) / p.OSY || p.OWF != (ow + p.OSX - 1) / p.OSX)
+      return false;
+  }
   // 32-bit byte offsets inside one tile: the images 128 output rows can touch, the weight panel, the output rows
   const double images = 130.0 / (double)(ohow > 0 ? ohow : 1) + 2.0;
   if (images * p.IH * p.IW * p.lda * 2.0 >= 4294967296.0) return false;

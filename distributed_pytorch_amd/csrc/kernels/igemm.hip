@@ -1202,6 +1202,8 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
+  if (p.flags & kIgemmRStrided)
+    throw std::invalid_argument("igemm: a compact strided accumulate is only implemented by the lean GEMM");
   if (dtype == kF32 && out_dtype == kF32) dispatch_tiles<float, float>(p, stream);
   else if (dtype == kBF16 && out_dtype == kBF16) dispatch_tiles<bf16_t, bf16_t>(p, stream);
   else if (dtype == kBF16 && out_dtype == kF32) dispatch_tiles<bf16_t, float>(p, stream);

@@ -11,11 +11,14 @@ namespace dpa {
 // kIgemmAxf: A is the RAW input z of a training-mode BatchNorm + ReLU; the kernel applies a = relu(a_scale[c] * z +
 // a_shift[c]) while it stages the A tile (the normalised activation is never written to memory).  16-bit dense
 // problems with 64-byte aligned reduction channels only (igemm_axf_ok).
+// kIgemmRStrided (lean GEMM only): R is compact [NB, OHF, OWF, ldc]; output pixel (y, x) adds R[y / OSY][x / OSX] when
+// y % OSY == 0 and x % OSX == 0 (powers of two) -- the data gradient of a strided 1x1 branch, never scattered into a
+// zero-filled full-size tensor.
 // kIgemmDense1: the caller guarantees ONE tap (0, 0, 0) -- a 1x1 convolution without padding or a Linear layer --
 // so every output pixel (oy, ox) reads input pixel (oy * SY, ox * SX): such launches may run the lean GEMM
 // (gemm_lean.hip: no tap bookkeeping, no padding masks).
 enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16,
-                        kIgemmAxf = 32, kIgemmDense1 = 64 };
+                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]

@@ -81,6 +81,7 @@ def bump_generation() -> None:
     _generation += 1
     _pending_bnred.clear()          # never carry a fused BN-backward slab across optimizer steps
     _pending_mask.clear()
+    _pending_compact.clear()
 
 
 class _WCache:
@@ -241,8 +242,10 @@ def _conv_out(i, k, s, p):
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
            scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False,
-           accum_mask=None, axf=None):
+           accum_mask=None, axf=None, rstride=None):
     """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
+    ``rstride``: (OHc, OWc, sy, sx) -- ``accum`` is the COMPACT gradient [NB, OHc, OWc, N] of a stride-s 1x1 branch
+    (added at the output pixels whose coordinates are multiples of s; lean GEMM only).
     ``row3``: the tap table is sorted into filter rows (dy, dx ascending, three taps per row): stride-1 "same"
     convolutions may use the filter-row kernel (one staged activation tile per three taps)."""
     flags = (C().IGEMM_RELU if relu else 0) | (C().IGEMM_ROW3 if row3 else 0)
@@ -261,6 +264,9 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
     if scatter is not None:
         flags |= C().IGEMM_SCATTER
         OHF, OWF, OSY, OSX, OY0, OX0 = scatter
+    if rstride is not None:
+        flags |= C().IGEMM_RSTRIDED
+        OHF, OWF, OSY, OSX = rstride
     C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
               _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs, _p(accum_mask),
@@ -338,6 +344,11 @@ class _ConvFn(torch.autograd.Function):
         _igemm(x, wc, y, bias_f, stats, taps, M, K, Cx, R * S, Cx, R * S * Cx, K, IH, IW, sh, sw, OH, OW,
                relu=relu, dtype=x.dtype, out_dtype=x.dtype, row3=(S == 3 and sw == 1 and pw == 1), axf=axf)
         ctx.axf = axf
+        # this convolution is the strided 1x1 branch of a block whose first convolution (the owner of the alias it
+        # reads) can add a COMPACT gradient: backward then returns [NB, OH, OW, Cx] instead of scattering it into a
+        # zero-filled full-size tensor (one fill + one scatter write + one full read less per downsample branch)
+        ctx.compact = bool(getattr(x_in, "_dpa_compact_ok", False) and (R, S, ph, pw) == (1, 1, 0, 0) and sh == sw
+                           and sh in (2, 4) and x is x_in and Cx == Cw and K % 32 == 0 and not relu)
         ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
         # x is the output of a training-mode BatchNorm: the data-gradient epilogue can produce that BN's
@@ -367,7 +378,15 @@ class _ConvFn(torch.autograd.Function):
             if ent is not None and ent[1] == dalias._version and ent[2] == _generation \
                     and ent[0].numel() * _vec(dalias.dtype) == dalias.numel():
                 amask = ent[0]
+        compact = None
+        if dalias is not None:
+            ent = _pending_compact.pop(dalias.data_ptr(), None)
+            if ent is not None and ent[3] == _generation and ent[0].data_ptr() == dalias.data_ptr() \
+                    and tuple(dalias.shape) == ent[4]:
+                compact = ent
         if dy is None:                      # only the alias was used downstream
+            if compact is not None:
+                dalias = _expand_compact(compact)
             if amask is not None:
                 dalias = apply_bit_mask(dalias, amask)
             return dalias, None, None, None, None, None, None, None, None, None, None
@@ -411,9 +430,30 @@ class _ConvFn(torch.autograd.Function):
             bnred = None
             if src is not None and src.uses == 1:                  # sole consumer of that BN's output
                 bnred = (src.x, x if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode)
-            dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
-                            accum_mask=amask)
+            if ctx.compact and dalias is None:
+                # compact gradient: a plain GEMM over the output grid; autograd receives a NaN placeholder of the
+                # input's shape (zero strides, no memory) that only the alias' owner knows how to replace -- anything
+                # else that touched it would turn the loss into NaN instead of silently training on garbage
+                dxc = torch.empty((NB, OH, OW, Cx), dtype=dy.dtype, device=dy.device)
+                _igemm(dy, conv_weight_t(weight, dy.dtype), dxc, None, None, _tap_table(dy.device, ((0, 0, 0),)),
+                       NB * OH * OW, Cx, K, 1, K, K, Cx, OH, OW, 1, 1, OH, OW, dtype=dy.dtype, out_dtype=dy.dtype)
+                fake = torch.full((1,), float("nan"), dtype=dy.dtype, device=dy.device)
+                dx = fake.expand(NB, IH, IW, Cx)
+                _pending_compact[dx.data_ptr()] = (fake, dxc, (sh, sw), _generation, (NB, IH, IW, Cx))
+            elif compact is not None:
+                if amask is not None or (bnred is not None and bnred[3] == 1):
+                    dalias, compact = _expand_compact(compact), None     # combinations the lean epilogue does not take
+                    dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
+                                    accum_mask=amask)
+                else:
+                    dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=compact[1], bnred=bnred,
+                                    accum_stride=compact[2])
+            else:
+                dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
+                                accum_mask=amask)
         elif dalias is not None:
+            if compact is not None:
+                dalias = _expand_compact(compact)
             dx = apply_bit_mask(dalias, amask) if amask is not None else dalias
         if ctx.needs_input_grad[1] and not wgrad_done:
             dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw), axf=axf)
@@ -463,6 +503,18 @@ _pending_bnred: Dict[int, tuple] = {}
 # Only produced for residuals tagged `_dpa_alias` (whose sole consumer is _ConvFn.backward, which applies the mask
 # inside the data-gradient epilogue): saves writing the masked copy (one activation-sized tensor per block).
 _pending_mask: Dict[int, tuple] = {}
+# data_ptr of the NaN placeholder a strided 1x1 branch returned as its input gradient -> (placeholder, compact gradient
+# [NB, OH, OW, C], (sy, sx), generation, full shape).  Consumed by the convolution that owns the alias the branch read.
+_pending_compact: Dict[int, tuple] = {}
+_COMPACT_DRES = os.environ.get("DPA_COMPACT_DRES", "1") == "1"
+
+
+def _expand_compact(ent) -> torch.Tensor:
+    """Cold paths: the full-size gradient a compact entry stands for."""
+    _, dxc, (sy, sx), _, shape = ent
+    full = torch.zeros(shape, dtype=dxc.dtype, device=dxc.device)
+    full[:, ::sy, ::sx] = dxc
+    return full
 _LAZY_DRES = os.environ.get("DPA_LAZY_DRES", "1") == "1"
 
 
@@ -508,7 +560,7 @@ def apply_bit_mask(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return (t.contiguous().view(-1, vec) * bits.to(t.dtype)).view(t.shape)
 
 
-def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accum_mask=None):
+def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accum_mask=None, accum_stride=None):
     NB, IH, IW, Cx = xshape
     K, Cw, R, S = weight.shape
     sh, sw = stride
@@ -519,6 +571,11 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
         raise ValueError("dgrad into a channel-padded input is not supported (stem has no input grad)")
     classes = _dgrad_classes(R, S, sh, sw, ph, pw)
     need_zero = any(len(t) == 0 for _, _, t in classes)
+    rstride = None
+    if accum_stride is not None:         # compact gradient of a strided 1x1 branch (see _ConvFn.backward)
+        if (R, S, sh, sw, ph, pw) != (1, 1, 1, 1, 0, 0) or accum is None or accum_mask is not None:
+            raise ValueError("compact strided accumulate: 1x1 stride-1 data gradients only")
+        rstride = (accum.shape[1], accum.shape[2], accum_stride[0], accum_stride[1])
     if accum is not None:
         accum = accum if accum.is_contiguous() else accum.contiguous()
     if accum_mask is not None and (need_zero or accum is None):
@@ -546,7 +603,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
             slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
         _igemm(dy, wt, dx, None, slab, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
                SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
-               bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask)
+               bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask, rstride=rstride)
         if slab is not None:
             _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version)
     return dx
@@ -660,6 +717,12 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
         # its gradient returns to _ConvFn.backward (and nowhere else): a BatchNorm that takes it as the residual may
         # hand back the UNMASKED gradient plus its ReLU bit mask instead of writing a masked copy
         alias._dpa_alias = True
+        K_, Cw_, R_, S_ = weight.shape
+        # the owner can add a compact strided gradient in its data-gradient epilogue (lean GEMM, 16-bit, dense 1x1)
+        alias._dpa_compact_ok = bool(_COMPACT_DRES and (R_, S_) == (1, 1) and tuple(stride) == (1, 1)
+                                     and tuple(padding) == (0, 0) and x.dtype in (torch.bfloat16, torch.float16)
+                                     and x.shape[-1] == Cw_ and Cw_ % 64 == 0 and K_ % 32 == 0 and x.is_contiguous()
+                                     and needs_input_grad)
     out = (y, stats) if want_stats else y
     return (out, alias) if skip else out
 

@@ -189,3 +189,35 @@ def test_linear_with_bias_starts_the_accumulators_at_the_bias(shape, relu):
         ref = ref.clamp_min(0)
     assert_close(y1, ref, torch.bfloat16, "linear + bias")
     assert_close(y1, y0.float(), torch.bfloat16, "lean vs general kernel", scale=0.5)
+
+
+@pytest.mark.parametrize("with_bn", [False, True])
+@pytest.mark.parametrize("case", [(3, 14, 256, 64, 2), (2, 9, 128, 96, 2), (2, 8, 64, 64, 4)])
+def test_compact_strided_accumulate_equals_scattered_gradient(case, with_bn):
+    """kIgemmRStrided: the gradient of a stride-s 1x1 branch is added from its compact [N, H/s, W/s, C] form; same
+    result as adding the zero-filled, scattered full-size tensor (odd extents: the compact grid is ceil(H / s))."""
+    hip_ops, C = _ops()
+    NB, H, Cin, Cout, s = case
+    dtype = torch.bfloat16
+    torch.manual_seed(sum(case) + with_bn)
+    dy = torch.randn(NB, H, H, Cout, device="cuda").to(dtype)
+    w = (torch.randn(Cout, Cin, 1, 1, device="cuda") * Cout ** -0.5).contiguous(memory_format=torch.channels_last)
+    Hc = (H + s - 1) // s
+    compact = torch.randn(NB, Hc, Hc, Cin, device="cuda").to(dtype)
+    full = torch.zeros(NB, H, H, Cin, device="cuda", dtype=dtype)
+    full[:, ::s, ::s] = compact
+    bn_x = torch.randn(NB, H, H, Cin, device="cuda").to(dtype)
+    coef = torch.rand(4, Cin, device="cuda") + 0.5
+    bits = torch.randint(0, 256, (NB * H * H * Cin // 8,), dtype=torch.uint8, device="cuda")
+    bnred = (bn_x, bits, coef, 3) if with_bn else None
+    a = hip_ops.conv_dgrad(dy, w, (NB, H, H, Cin), (1, 1), (0, 0), accum=full.clone(), bnred=bnred)
+    sa = hip_ops._pending_bnred.pop(a.data_ptr())[0].clone() if with_bn else None
+    b = hip_ops.conv_dgrad(dy, w, (NB, H, H, Cin), (1, 1), (0, 0), accum=compact, bnred=bnred, accum_stride=(s, s))
+    sb = hip_ops._pending_bnred.pop(b.data_ptr())[0].clone() if with_bn else None
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if with_bn:
+        assert torch.equal(sa, sb)
+    ref = torch.einsum("nhwk,kc->nhwc", dy.float(), w.to(dtype).float().reshape(Cout, Cin)) + full.float()
+    # (the epilogue adds R to the ROUNDED product and rounds again: up to one more ulp where the two cancel)
+    assert_close(b, ref, dtype, "dgrad + compact accumulate", scale=2)

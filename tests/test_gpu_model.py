@@ -275,6 +275,49 @@ def test_lazy_residual_gradient_equals_materialised(arch):
         assert torch.allclose(g1[n], g2[n], rtol=1e-5, atol=1e-7), n
 
 
+def test_compact_downsample_gradient_equals_scattered():
+    """The strided 1x1 downsample branch of a bottleneck returns its input gradient in compact form (a NaN placeholder
+    travels through autograd); the block's first convolution adds it in its data-gradient epilogue.  Bit-identical
+    to the zero-filled, scattered tensor, the path is really taken (3 downsample branches in ResNet-50), and nothing
+    is left pending."""
+    from distributed_pytorch_amd import amp, models
+    from distributed_pytorch_amd.ops import hip_ops
+    from distributed_pytorch_amd.optim import FusedSGD
+
+    torch.manual_seed(2)
+    base = models.create_model("resnet50", num_classes=100).cuda()
+    x = torch.randint(0, 256, (8, 96, 96, 3), dtype=torch.uint8, device="cuda")
+    t = torch.randint(0, 100, (8,), device="cuda")
+    res = []
+    try:
+        for compact in (True, False):
+            hip_ops._COMPACT_DRES = compact
+            amp.state().reset()
+            model = copy.deepcopy(base)
+            opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9)
+            model, opt = amp.initialize(model, opt, opt_level="O2", dtype="bf16")
+            seen = []
+            orig = hip_ops._igemm
+
+            def spy(*a, **k):
+                seen.append(k.get("rstride") is not None)
+                return orig(*a, **k)
+
+            hip_ops._igemm = spy
+            try:
+                res.append(_run(model, x, t))
+            finally:
+                hip_ops._igemm = orig
+            assert sum(seen) == (3 if compact else 0)
+            assert not hip_ops._pending_compact
+    finally:
+        hip_ops._COMPACT_DRES = True
+    (o1, l1, g1), (o2, l2, g2) = res
+    assert torch.equal(o1, o2) and l1 == l2 and torch.isfinite(torch.tensor(l1))
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+
+
 @pytest.mark.parametrize("arch", ["regnet_y_128gf", "efficientnet_b7", "convnext_large", "densenet201", "resnext101_64x4d",
                                   "vgg19_bn", "wide_resnet101_2", "regnet_x_32gf", "vit_h_14", "vit_l_16", "swin_b",
                                   "swin_v2_b", "shufflenet_v2_x1_5"])
