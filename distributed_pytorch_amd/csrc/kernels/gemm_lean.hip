@@ -58,7 +58,7 @@ int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 fo
 // BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false>
+          bool BIAS = false, bool AXF = false>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BM = 128;
@@ -142,7 +142,21 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   // PF register sets: PF K tiles are in flight while one is consumed (a K step computes for ~300 cycles, a load
   // takes 1-2k under load: with one tile in flight every K step pays most of a memory latency)
   u32x4_t ra[PF][A_IT], rb[PF][B_IT];
+  // AXF (kIgemmAxf): A is the raw input of a BatchNorm + ReLU; relu(scale[c] * z + shift[c]) is applied when a tile
+  // goes from registers to LDS (bit-identical to the stand-alone pass, igemm.hip).  The (scale, shift) table sits
+  // behind the two stages, one 64-byte entry per 8-channel chunk; a thread stages ONE chunk column per K tile.
+  float* const axf_tab = reinterpret_cast<float*>(smem + 2 * STAGE);
+  int axf_q[PF] = {}, axf_kt = 0;
+  if constexpr (AXF) {
+    for (int c = tid; c < p.Cred; c += 256) {
+      float* t = axf_tab + (c / VEC) * (2 * VEC) + (c % VEC);
+      t[0] = p.a_scale[c];
+      t[VEC] = p.a_shift[c];
+    }
+    __syncthreads();
+  }
   auto load_tile = [&](int set) __attribute__((always_inline)) {
+    if constexpr (AXF) axf_q[set] = (axf_kt++) * CPR + ch;
     if ((ABL == 3 || ABL >= 5) && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T)) {
       Ag += BKB;      // (keeps the first-tile test of store_tile exact)
       return;
@@ -156,8 +170,22 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   };
   auto store_tile = [&](int set, int stage) __attribute__((always_inline)) {
     if (ABL >= 5 && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T) + BKB) return;
+    float asc[VEC], ash[VEC];
+    if constexpr (AXF) {
+      const float4* t4 = reinterpret_cast<const float4*>(axf_tab + axf_q[set] * (2 * VEC));
+      const float4 s0 = t4[0], s1 = t4[1], h0 = t4[2], h1 = t4[3];
+      asc[0] = s0.x; asc[1] = s0.y; asc[2] = s0.z; asc[3] = s0.w; asc[4] = s1.x; asc[5] = s1.y; asc[6] = s1.z; asc[7] = s1.w;
+      ash[0] = h0.x; ash[1] = h0.y; ash[2] = h0.z; ash[3] = h0.w; ash[4] = h1.x; ash[5] = h1.y; ash[6] = h1.z; ash[7] = h1.w;
+    }
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_a + stage * STAGE + i * RPI * LDR) = ra[set][i];
+    for (int i = 0; i < A_IT; ++i) {
+      u32x4_t v = ra[set][i];
+      if constexpr (AXF) {
+        const uint4 r = bn_relu_chunk<T>(make_uint4(v.x, v.y, v.z, v.w), asc, ash);
+        v = u32x4_t{r.x, r.y, r.z, r.w};
+      }
+      *reinterpret_cast<u32x4_t*>(wr_a + stage * STAGE + i * RPI * LDR) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4_t*>(wr_b + stage * STAGE + i * RPI * LDR) = rb[set][i];
   };
@@ -459,17 +487,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 }
 
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false>
+          bool BIAS = false, bool AXF = false>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
   constexpr int epi_bytes = 128 * (BN * 2 + 16);
   constexpr int red_bytes = 9 * BN * 4;
-  constexpr int max_lds = 2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes;
+  constexpr int max_lds = (2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes) + (AXF ? 8 * 2048 : 0);
   int lds = (p.Cred * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
+  if (AXF) lds = 2 * stage_bytes + 8 * p.Cred;            // (scale, shift) table behind both stages
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -484,6 +513,10 @@ template <typename T, int BN, int BKB, int MINB, int PF>
 void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   const bool bnb = p.flags & kIgemmBnBwd;
   const bool stats = p.stats != nullptr && !bnb, racc = p.R != nullptr;
+  if (p.flags & kIgemmAxf) {           // forward with BN + ReLU applied on load: always wants the next BN's statistics
+    launch_lean<T, BN, BKB, MINB, PF, true, false, false, false, 0, false, true>(p, stream);
+    return;
+  }
   if (p.bias != nullptr) {             // Linear forward (gemm_lean_try admits a bias only on the plain variant)
     launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true>(p, stream);
     return;
@@ -550,7 +583,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if (g_lean_mode == 0 && !(p.flags & kIgemmRStrided)) return false;    // (a compact accumulate has no other kernel)
   if (dtype != out_dtype || (dtype != kBF16 && dtype != kF16)) return false;
   if (!(p.flags & kIgemmDense1) || p.ntaps != 1) return false;
-  if (p.flags & (kIgemmScatter | kIgemmAxf)) return false;
+  if (p.flags & kIgemmScatter) return false;
   if (p.groups > 1) return false;
   const bool bnb = p.flags & kIgemmBnBwd;
   // bias (+ ReLU): Linear layers, plain epilogue only
@@ -568,6 +601,9 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if ((oh - 1) * p.SY >= p.IH || (ow - 1) * p.SX >= p.IW) return false;
   const bool strided = !(p.SY == 1 && p.SX == 1 && (long)p.IH * p.IW == ohow && p.IW == ow);
   if (strided && (p.R != nullptr || bnb || p.bias != nullptr)) return false;
+  if ((p.flags & kIgemmAxf) && (p.stats == nullptr || p.R != nullptr || bnb || p.bias != nullptr || strided ||
+                                p.a_scale == nullptr || p.a_shift == nullptr || p.Cred > 2048))
+    return false;
   if (p.flags & kIgemmRStrided) {      // compact R of a strided 1x1 branch (see the kernel's prefetch)
     auto pow2 = [](int v) { return v >= 1 && (v & (v - 1)) == 0; };
     if (p.R == nullptr || p.r_mask != nullptr || strided || !pow2(p.OSY) || !pow2(p.OSX) ||
