@@ -109,13 +109,15 @@ struct AttnArgs {
   int B, H, S, D, nbias, nsplit;
 };
 
-constexpr int kAttnMaxDB = 4;      // D <= 128
+constexpr int kAttnMaxDB = 4;      // D <= 128.  The kernels are instantiated for MDB = 1, 2, 4 blocks of 32 head
+                                   // channels (D <= 32 / 64 / 128): accumulators and operand fragments are sized by MDB, and
+                                   // sizing them for 128 cost D = 64 heads half their occupancy (419 registers, 1 wave per SIMD)
 
 // ------------------------------------------------------------------------------------------------ forward / dQ
 // BWD = false: O and log-sum-exp.  BWD = true: dQ (same loop + the dP product).  Workgroup = NW waves = 32 * NW queries of
 // one (b, h); K and V (all S tokens) are staged in LDS once per workgroup (NW = 4 for S > 64: half the staging traffic
 // and twice the waves per LDS byte; NW = 2 for single-window problems, where 4 waves would idle).
-template <typename T, bool BWD, int NW>
+template <typename T, bool BWD, int NW, int MDB>
 __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,9 +137,9 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
   const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;       // this lane's query row
   const bool qok = q < S;
   // Q (and dO) fragments straight from global memory: row q, 8 elements at 16*ks + 8*lh
-  uint4 qf[2 * kAttnMaxDB], gf[2 * kAttnMaxDB];
+  uint4 qf[2 * MDB], gf[2 * MDB];
 #pragma unroll
-  for (int ks = 0; ks < 2 * kAttnMaxDB; ++ks) {
+  for (int ks = 0; ks < 2 * MDB; ++ks) {
     qf[ks] = gf[ks] = make_uint4(0u, 0u, 0u, 0u);
     const int c = ks * 16 + lh * 8;
     if (ks < KS && qok && c < D) {
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
   }
   __syncthreads();
 
-  f32x16_t acc[kAttnMaxDB];
+  f32x16_t acc[MDB];
 #pragma unroll
-  for (int d = 0; d < kAttnMaxDB; ++d)
+  for (int d = 0; d < MDB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2 * kAttnMaxDB; ++ks)
+    for (int ks = 0; ks < 2 * MDB; ++ks)
       if (ks < KS) AMma<T>::run(sc, frag_direct(sk, LD, kb * 32 + l31, ks, lh), qf[ks]);
     float p[16];
     float mblk = -INFINITY;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
       l_run = l_run * alpha + lsum;
       m_run = m_new;
 #pragma unroll
-      for (int d = 0; d < kAttnMaxDB; ++d)
+      for (int d = 0; d < MDB; ++d)
         if (d < NDB)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 2 * kAttnMaxDB; ++ks)
+      for (int ks = 0; ks < 2 * MDB; ++ks)
         if (ks < KS) AMma<T>::run(dp, frag_direct(sv, LD, kb * 32 + l31, ks, lh), gf[ks]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
       for (int j = 0; j < 8; ++j) half[j] = p[8 * s2 + j];
       const uint4 pf = pack8<T>(half);
 #pragma unroll
-      for (int d = 0; d < kAttnMaxDB; ++d)
+      for (int d = 0; d < MDB; ++d)
         if (d < NDB) AMma<T>::run(acc[d], frag_tr(tile, LD, kb * 32 + 16 * s2, d * 32, lane), pf);
     }
   }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
     if (qok) {
       T* o = reinterpret_cast<T*>(a.out) + ((long)b * S + q) * H * D + (long)h * D;
 #pragma unroll
-      for (int d = 0; d < kAttnMaxDB; ++d)
+      for (int d = 0; d < MDB; ++d)
         if (d < NDB)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
   } else if (qok) {
     T* o = reinterpret_cast<T*>(a.dqkv) + ((long)b * S + q) * row_ld + (long)h * D;
 #pragma unroll
-    for (int d = 0; d < kAttnMaxDB; ++d)
+    for (int d = 0; d < MDB; ++d)
       if (d < NDB)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
 // Workgroup = 2 waves = 64 keys of head h; it walks batch entries b = split, split + nsplit, ...  Q and dO of the
 // current (b, h) are staged in LDS (all S tokens), the wave's own K / V rows are read as fragments from global memory.
 // DBIAS (S <= 64: one workgroup covers every key): dS accumulates in registers over the strip of batch entries.
-template <typename T, bool DBIAS, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
+template <typename T, bool DBIAS, int NW, int MDB>
+__global__ __launch_bounds__(64 * NW, MDB <= 1 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -307,9 +309,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
       s_lse[i] = i < S ? a.lse[((long)b * H + h) * S + i] : 0.f;
       s_delta[i] = i < S ? a.delta[((long)b * H + h) * S + i] : 0.f;
     }
-    uint4 kf[2 * kAttnMaxDB], vf[2 * kAttnMaxDB];
+    uint4 kf[2 * MDB], vf[2 * MDB];
 #pragma unroll
-    for (int ks = 0; ks < 2 * kAttnMaxDB; ++ks) {
+    for (int ks = 0; ks < 2 * MDB; ++ks) {
       kf[ks] = vf[ks] = make_uint4(0u, 0u, 0u, 0u);
       const int c = ks * 16 + lh * 8;
       if (ks < KS && kok && c < D) {
@@ -320,9 +322,9 @@ __global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
     const float* bias = a.bias ? a.bias + ((long)(b % a.nbias) * H + h) * S * S : nullptr;
     __syncthreads();
 
-    f32x16_t dk[kAttnMaxDB], dv[kAttnMaxDB];
+    f32x16_t dk[MDB], dv[MDB];
 #pragma unroll
-    for (int d = 0; d < kAttnMaxDB; ++d)
+    for (int d = 0; d < MDB; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
 
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 2 * kAttnMaxDB; ++ks)
+      for (int ks = 0; ks < 2 * MDB; ++ks)
         if (ks < KS) {
           AMma<T>::run(sc, frag_direct(sq, LD, qb * 32 + l31, ks, lh), kf[ks]);
           AMma<T>::run(dp, frag_direct(sg, LD, qb * 32 + l31, ks, lh), vf[ks]);
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
         }
         const uint4 pf = pack8<T>(hp), df = pack8<T>(hd);
 #pragma unroll
-        for (int d = 0; d < kAttnMaxDB; ++d)
+        for (int d = 0; d < MDB; ++d)
           if (d < NDB) {
             AMma<T>::run(dv[d], frag_tr(sg, LD, qb * 32 + 16 * s2, d * 32, lane), pf);   // dV += P^T dO
             AMma<T>::run(dk[d], frag_tr(sq, LD, qb * 32 + 16 * s2, d * 32, lane), df);   // dK += dS^T Q
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kv_kernel(const AttnArgs a) {
     if (kok) {
       T* o = reinterpret_cast<T*>(a.dqkv) + ((long)b * S + key) * row_ld + (long)h * D;
 #pragma unroll
-      for (int d = 0; d < kAttnMaxDB; ++d)
+      for (int d = 0; d < MDB; ++d)
         if (d < NDB)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -623,14 +625,17 @@ void attn_fwd_launch(const void* qkv, void* out, float* lse, const float* bias, 
   const int lds = lds_bytes(S, D, false);
   const int nw = S > 64 ? 4 : 2;
   dim3 grid(ceil_div(S, 32 * nw), B * H);
+#define DPA_ATTN_FWD2(T, NW, MDB)                                                            \
+  set_lds(attn_q_kernel<T, false, NW, MDB>, lds);                                            \
+  hipLaunchKernelGGL((attn_q_kernel<T, false, NW, MDB>), grid, dim3(64 * NW), lds, s, a);
 #define DPA_ATTN_FWD(T, NW)                                                                  \
-  set_lds(attn_q_kernel<T, false, NW>, lds);                                                 \
-  hipLaunchKernelGGL((attn_q_kernel<T, false, NW>), grid, dim3(64 * NW), lds, s, a);
+  if (D <= 32) { DPA_ATTN_FWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_FWD2(T, NW, 2) } else { DPA_ATTN_FWD2(T, NW, 4) }
   if (dtype == kBF16) {
     if (nw == 4) { DPA_ATTN_FWD(bf16_t, 4) } else { DPA_ATTN_FWD(bf16_t, 2) }
   } else {
     if (nw == 4) { DPA_ATTN_FWD(f16_t, 4) } else { DPA_ATTN_FWD(f16_t, 2) }
   }
+#undef DPA_ATTN_FWD2
 #undef DPA_ATTN_FWD
   DPA_CHECK_HIP(hipGetLastError());
 }
@@ -657,23 +662,26 @@ void attn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
   const int lds_q = lds_bytes(S, D, false), lds_kv = lds_bytes(S, D, true);
   const int nw = S > 64 ? 4 : 2;
   dim3 gq(ceil_div(S, 32 * nw), B * H), gkv(ceil_div(S, 32 * nw), a.nsplit * H);
+#define DPA_ATTN_BWD2(T, NW, MDB)                                                                                    \
+  set_lds(attn_q_kernel<T, true, NW, MDB>, lds_q);                                                                   \
+  hipLaunchKernelGGL((attn_q_kernel<T, true, NW, MDB>), gq, dim3(64 * NW), lds_q, s, a);                             \
+  if (dbias != nullptr) {                                                                                            \
+    set_lds(attn_kv_kernel<T, true, 2, MDB>, lds_kv);                                                                \
+    hipLaunchKernelGGL((attn_kv_kernel<T, true, 2, MDB>), gkv, dim3(128), lds_kv, s, a);                             \
+  } else {                                                                                                           \
+    set_lds(attn_kv_kernel<T, false, NW, MDB>, lds_kv);                                                              \
+    hipLaunchKernelGGL((attn_kv_kernel<T, false, NW, MDB>), gkv, dim3(64 * NW), lds_kv, s, a);                       \
+  }
 #define DPA_ATTN_BWD(T, NW)                                                                                          \
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(dgrid), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, rows, H, \
                      S, D);                                                                                          \
-  set_lds(attn_q_kernel<T, true, NW>, lds_q);                                                                        \
-  hipLaunchKernelGGL((attn_q_kernel<T, true, NW>), gq, dim3(64 * NW), lds_q, s, a);                                  \
-  if (dbias != nullptr) {                                                                                            \
-    set_lds(attn_kv_kernel<T, true, 2>, lds_kv);                                                                     \
-    hipLaunchKernelGGL((attn_kv_kernel<T, true, 2>), gkv, dim3(128), lds_kv, s, a);                                  \
-  } else {                                                                                                           \
-    set_lds(attn_kv_kernel<T, false, NW>, lds_kv);                                                                   \
-    hipLaunchKernelGGL((attn_kv_kernel<T, false, NW>), gkv, dim3(64 * NW), lds_kv, s, a);                            \
-  }
+  if (D <= 32) { DPA_ATTN_BWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_BWD2(T, NW, 2) } else { DPA_ATTN_BWD2(T, NW, 4) }
   if (dtype == kBF16) {
     if (nw == 4) { DPA_ATTN_BWD(bf16_t, 4) } else { DPA_ATTN_BWD(bf16_t, 2) }
   } else {
     if (nw == 4) { DPA_ATTN_BWD(f16_t, 4) } else { DPA_ATTN_BWD(f16_t, 2) }
   }
+#undef DPA_ATTN_BWD2
 #undef DPA_ATTN_BWD
   DPA_CHECK_HIP(hipGetLastError());
 }
