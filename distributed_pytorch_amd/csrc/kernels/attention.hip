@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
 // current (b, h) are staged in LDS (all S tokens), the wave's own K / V rows are read as fragments from global memory.
 // DBIAS (S <= 64: one workgroup covers every key): dS accumulates in registers over the strip of batch entries.
 template <typename T, bool DBIAS, int NW, int MDB>
-__global__ __launch_bounds__(64 * NW, MDB <= 1 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, MDB <= 2 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
