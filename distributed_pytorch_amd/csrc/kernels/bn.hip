@@ -17,6 +17,7 @@
 #include "../common.h"
 #include "kernels.h"
 #include <stdexcept>
+#include <type_traits>
 
 namespace dpa {
 namespace {
@@ -27,8 +28,10 @@ constexpr int kBnThreads = 256;
 // SMOOTH (MODE 1 only): the BN is followed by a smooth activation ((relu >> 4) & 7, see common.h act_slope) fused into
 // the apply pass; dy is multiplied by its slope at z = scale*x + shift, recomputed here.  A separate instantiation, so
 // the ReLU / no-activation kernels of the ResNet hot path are not touched.
-template <typename T, int MODE, bool SMOOTH = false>
-__global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ x,
+// RM (the ReLU-mask source, relu & 3 below) and NT (streaming loads) are compile-time: as run-time branches they doubled
+// the load paths and left the bf16 kernel at 194 VGPRs = 2 waves per SIMD, 3.1 TB/s; sized per variant it holds 4.
+template <typename T, int MODE, bool SMOOTH = false, int RM = 0, bool NT = false>
+__global__ __launch_bounds__(kBnThreads, 4) void col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ x,
                                                                 const T* __restrict__ y, long M, int C,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu,
@@ -50,23 +53,24 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
   // from x (no residual): the output tensor is not read at all, 3 mask = one BIT per element written by the
   // forward apply pass (`y` then points at bytes, one per 16-byte chunk): 1/16 of the output's bytes.
   // relu & 4: ReLU6, the mask also needs y < 6.
-  const int rm = relu & 3;
+  constexpr int rm = RM;
+  constexpr bool ntl = NT;                     // streaming loads (tuning hook)
   const bool clip = (relu & 4) != 0;
-  const bool ntl = (relu & 256) != 0;          // streaming loads (tuning hook)
-  float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[VEC], sh[VEC];
+  constexpr bool kCoef = MODE == 1 && (RM == 2 || SMOOTH);
+  float s1[VEC], s2[VEC], mu[VEC], is[VEC], sc[kCoef ? VEC : 1], sh[kCoef ? VEC : 1];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     s1[j] = s2[j] = 0.f;
     mu[j] = 0.f;
     is[j] = 1.f;
-    sc[j] = sh[j] = 0.f;
+    if constexpr (kCoef) sc[j] = sh[j] = 0.f;
   }
   if (MODE == 1 && active) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = mean[c0 + j];
       is[j] = invstd[c0 + j];
-      if (rm == 2 || SMOOTH) {
+      if constexpr (kCoef) {
         sc[j] = scale[c0 + j];
         sh[j] = shift[c0 + j];
       }
@@ -98,13 +102,16 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
       for (int j = 0; j < VEC; ++j) {
         float d = va.get(j);
         const float xv = vx.get(j);
-        if (rm == 3) {
+        if constexpr (rm == 3) {
           if (!((bits >> j) & 1u)) d = 0.f;
-        } else if (rm != 0) {
-          const float yv = rm == 1 ? vy.get(j) : to_float(from_float<T>(sc[j] * xv + sh[j]));
+        } else if constexpr (rm == 1) {
+          const float yv = vy.get(j);
+          if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
+        } else if constexpr (rm == 2) {
+          const float yv = to_float(from_float<T>(sc[kCoef ? j : 0] * xv + sh[kCoef ? j : 0]));
           if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
         }
-        if constexpr (SMOOTH) d *= act_slope((relu >> 4) & 7, sc[j] * xv + sh[j]);
+        if constexpr (SMOOTH) d *= act_slope((relu >> 4) & 7, sc[kCoef ? j : 0] * xv + sh[kCoef ? j : 0]);
         const float xh = (xv - mu[j]) * is[j];
         s1[j] += d;
         s2[j] += d * xh;
@@ -115,32 +122,33 @@ __global__ __launch_bounds__(kBnThreads) void col_reduce_kernel(const T* __restr
     long r = r_begin + rl;
     // 4 rows per trip, every load issued before the first use (the summation order stays fixed)
     for (; r + 3 * rp < r_end; r += 4 * rp) {
-      Vec16<T> va[4], vx[4], vy[4];
+      Vec16<T> va[4], vx[MODE == 1 ? 4 : 1], vy[MODE == 1 && rm == 1 ? 4 : 1];
       uint32_t mb[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = (size_t)(r + u * rp) * C + c0;
-        if (MODE == 1 && rm == 3) mb[u] = reinterpret_cast<const uint8_t*>(y)[off / VEC];
-        if (ntl) {
+        if constexpr (MODE == 1 && rm == 3) mb[u] = reinterpret_cast<const uint8_t*>(y)[off / VEC];
+        if constexpr (ntl) {
           va[u].load_nt(a + off);
-          if (MODE == 1) vx[u].load_nt(x + off);
-          if (MODE == 1 && rm == 1) vy[u].load_nt(y + off);
+          if constexpr (MODE == 1) vx[u].load_nt(x + off);
+          if constexpr (MODE == 1 && rm == 1) vy[u].load_nt(y + off);
         } else {
           va[u].load(a + off);
-          if (MODE == 1) vx[u].load(x + off);
-          if (MODE == 1 && rm == 1) vy[u].load(y + off);
+          if constexpr (MODE == 1) vx[u].load(x + off);
+          if constexpr (MODE == 1 && rm == 1) vy[u].load(y + off);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) accumulate(va[u], vx[u], vy[u], mb[u]);
+      for (int u = 0; u < 4; ++u) accumulate(va[u], vx[MODE == 1 ? u : 0], vy[MODE == 1 && rm == 1 ? u : 0], mb[u]);
     }
     for (; r < r_end; r += rp) {
       const size_t off = (size_t)r * C + c0;
       Vec16<T> va, vx, vy;
       va.load(a + off);
-      if (MODE == 1) vx.load(x + off);
-      if (MODE == 1 && rm == 1) vy.load(y + off);
-      const uint32_t mb = (MODE == 1 && rm == 3) ? reinterpret_cast<const uint8_t*>(y)[off / VEC] : 0u;
+      if constexpr (MODE == 1) vx.load(x + off);
+      if constexpr (MODE == 1 && rm == 1) vy.load(y + off);
+      uint32_t mb = 0u;
+      if constexpr (MODE == 1 && rm == 3) mb = reinterpret_cast<const uint8_t*>(y)[off / VEC];
       accumulate(va, vx, vy, mb);
     }
   }
@@ -445,7 +453,11 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, f
   }
 }
 
-int g_bn_grid = 256 * 8;     // tuning hooks (bench/bn_layers.py): workgroups of the streaming kernels, unroll
+// Workgroups of the grid-stride streaming kernels.  NOT a power of two: a lane's successive chunks (and the chunks the
+// chip reads at the same moment in different streams) are grid * 4 KiB apart, and with 2048 / 4096 workgroups that
+// stride maps them onto the same HBM channels -- 1280 (5 per CU, one resident round) is 8-11 % faster than 2048 on
+// the batch-1024 tensors, 1024 / 2048 / 4096 are the slow ones (profiles/r2/bn_stream_grid.txt).
+int g_bn_grid = 256 * 5;     // tuning hooks (bench/bn_layers.py, DPA_BN_GRID): workgroups of the streaming kernels, unroll
 int g_bn_unroll = 1;
 long g_nt_min_bytes = 32l << 20;    // tensors at least this large are streamed with nontemporal loads / stores
                                     // (they cannot stay in the 256 MB Infinity Cache anyway): +1.5 % on the bench
@@ -687,6 +699,191 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- lean streaming variants of the two apply passes -----------------------------------------------------------------
+// The generic kernels above decide the mask source, streaming hints and the residual at run time; every such branch
+// doubles a load path and the bf16 instantiations ended at 74-100 VGPRs with ONE 16-byte chunk per stream in flight per
+// lane: 4.4-4.8 TB/s on the batch-1024 tensors (scratch/bn_stream_bench.py).  Here everything that shapes the loop is a
+// template parameter, U chunks per stream are requested before the first use, and the register budget is capped so
+// that DPA_BN_OCC waves per SIMD stay resident.  Taken when a thread's channel chunk is loop invariant (grid stride a
+// multiple of the chunk-column count) and the tensor is walked forwards.
+#ifndef DPA_BN_U
+#define DPA_BN_U 2
+#endif
+#ifndef DPA_BN_OCC
+#define DPA_BN_OCC 6
+#endif
+
+// RES: 0 no residual, 1 y = act(bn(x) + res), 2 y = act(bn(x) + res_scale * res + res_shift)
+template <typename T, int RES, bool MASK, bool NT, int U>
+__global__ __launch_bounds__(256, DPA_BN_OCC) void bn_apply_fast_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long nchunks, int cc,
+    const float* __restrict__ scale, const float* __restrict__ shift, int relu, uint8_t* __restrict__ mask,
+    const float* __restrict__ res_scale, const float* __restrict__ res_shift) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nchunks) return;
+  const int c0 = (int)(i % cc) * VEC;
+  float scv[VEC], shv[VEC], rsc[RES == 2 ? VEC : 1], rsh[RES == 2 ? VEC : 1];
+  load_coef<VEC>(scale, c0, scv);
+  load_coef<VEC>(shift, c0, shv);
+  if constexpr (RES == 2) {
+    load_coef<VEC>(res_scale, c0, rsc);
+    load_coef<VEC>(res_shift, c0, rsh);
+  }
+  const float lo = (relu & 3) ? 0.f : -INFINITY, hi = (relu & 4) ? 6.f : INFINITY;
+  auto one = [&](const Vec16<T>& vx, const Vec16<T>& vr, long q) {
+    Vec16<T> vo;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = vx.get(j) * scv[j] + shv[j];
+      if constexpr (RES == 1) v += vr.get(j);
+      if constexpr (RES == 2) v += vr.get(j) * rsc[j] + rsh[j];      // same association as the generic kernel
+      vo.set(j, fminf(fmaxf(v, lo), hi));
+    }
+    if constexpr (NT) vo.store_nt(y + q * VEC);
+    else vo.store(y + q * VEC);
+    if constexpr (MASK) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) m |= (vo.get(j) > 0.f ? 1u : 0u) << j;
+      mask[q] = (uint8_t)m;
+    }
+  };
+  for (; i + (U - 1) * stride < nchunks; i += U * stride) {
+    Vec16<T> vx[U], vr[RES ? U : 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long q = i + u * stride;
+      if constexpr (NT) {
+        vx[u].load_nt(x + q * VEC);
+        if constexpr (RES != 0) vr[u].load_nt(res + q * VEC);
+      } else {
+        vx[u].load(x + q * VEC);
+        if constexpr (RES != 0) vr[u].load(res + q * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(vx[u], vr[RES ? u : 0], i + u * stride);
+  }
+  for (; i < nchunks; i += stride) {
+    Vec16<T> vx, vr;
+    vx.load(x + i * VEC);
+    if constexpr (RES != 0) vr.load(res + i * VEC);
+    one(vx, vr, i);
+  }
+}
+
+// dx = A * dy_m + B * x + K, optional second output dres = dy_m; RM = the mask source (relu & 3, see col_reduce_kernel)
+template <typename T, int RM, bool DRES, bool NT, int U>
+__global__ __launch_bounds__(256, DPA_BN_OCC) void bn_bwd_apply_fast_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
+    long nchunks, int cc, int C, const float* __restrict__ coef, int relu) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nchunks) return;
+  const int c0 = (int)(i % cc) * VEC;
+  float ca[VEC], cb[VEC], ck[VEC], sc[RM == 2 ? VEC : 1], sh[RM == 2 ? VEC : 1];
+  load_coef<VEC>(coef, c0, ca);
+  load_coef<VEC>(coef + C, c0, cb);
+  load_coef<VEC>(coef + 2 * C, c0, ck);
+  if constexpr (RM == 2) {
+    load_coef<VEC>(coef + 3 * C, c0, sc);
+    load_coef<VEC>(coef + 4 * C, c0, sh);
+  }
+  const bool clip = (relu & 4) != 0;
+  auto one = [&](const Vec16<T>& vd, const Vec16<T>& vx, const Vec16<T>& vy, uint32_t mbits, long q) {
+    Vec16<T> vo, vr;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float d = vd.get(j);
+      const float xv = vx.get(j);
+      if constexpr (RM == 3) {
+        if (!((mbits >> j) & 1u)) d = 0.f;
+      } else if constexpr (RM == 1) {
+        const float yv = vy.get(j);
+        if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
+      } else if constexpr (RM == 2) {
+        const float yv = to_float(from_float<T>(sc[j] * xv + sh[j]));
+        if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
+      }
+      vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
+      if constexpr (DRES) vr.set(j, d);
+    }
+    if constexpr (NT) vo.store_nt(dx + q * VEC);
+    else vo.store(dx + q * VEC);
+    if constexpr (DRES) {
+      if constexpr (NT) vr.store_nt(dres + q * VEC);
+      else vr.store(dres + q * VEC);
+    }
+  };
+  for (; i + (U - 1) * stride < nchunks; i += U * stride) {
+    Vec16<T> vd[U], vx[U], vy[RM == 1 ? U : 1];
+    uint32_t mb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long q = i + u * stride;
+      mb[u] = 0u;
+      if constexpr (RM == 3) mb[u] = reinterpret_cast<const uint8_t*>(y)[q];
+      if constexpr (NT) {
+        vd[u].load_nt(dy + q * VEC);
+        vx[u].load_nt(x + q * VEC);
+        if constexpr (RM == 1) vy[u].load_nt(y + q * VEC);
+      } else {
+        vd[u].load(dy + q * VEC);
+        vx[u].load(x + q * VEC);
+        if constexpr (RM == 1) vy[u].load(y + q * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(vd[u], vx[u], vy[RM == 1 ? u : 0], mb[u], i + u * stride);
+  }
+  for (; i < nchunks; i += stride) {
+    Vec16<T> vd, vx, vy;
+    vd.load(dy + i * VEC);
+    vx.load(x + i * VEC);
+    if constexpr (RM == 1) vy.load(y + i * VEC);
+    uint32_t mb = 0u;
+    if constexpr (RM == 3) mb = reinterpret_cast<const uint8_t*>(y)[i];
+    one(vd, vx, vy, mb, i);
+  }
+}
+
+template <typename T>
+void bn_apply_fast(int grid, hipStream_t s, const void* x, const void* res, void* y, long nchunks, int cc,
+                   const float* scale, const float* shift, int relu, uint8_t* mask, const float* res_scale,
+                   const float* res_shift, bool nt) {
+  auto go = [&](auto resc, auto maskc, auto ntc) {
+    hipLaunchKernelGGL((bn_apply_fast_kernel<T, decltype(resc)::value, decltype(maskc)::value, decltype(ntc)::value,
+                                             DPA_BN_U>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)res, (T*)y,
+                       nchunks, cc, scale, shift, relu, mask, res_scale, res_shift);
+  };
+  auto go2 = [&](auto resc, auto maskc) { nt ? go(resc, maskc, std::true_type{}) : go(resc, maskc, std::false_type{}); };
+  auto go1 = [&](auto resc) { mask != nullptr ? go2(resc, std::true_type{}) : go2(resc, std::false_type{}); };
+  if (res == nullptr) go1(std::integral_constant<int, 0>{});
+  else if (res_scale == nullptr) go1(std::integral_constant<int, 1>{});
+  else go1(std::integral_constant<int, 2>{});
+}
+
+template <typename T>
+void bn_bwd_apply_fast(int grid, hipStream_t s, const void* dy, const void* x, const void* y, void* dx, void* dres,
+                       long nchunks, int cc, int C, const float* coef, int relu, bool nt) {
+  auto go = [&](auto rmc, auto dresc, auto ntc) {
+    hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, decltype(rmc)::value, decltype(dresc)::value, decltype(ntc)::value,
+                                                 DPA_BN_U>), dim3(grid), dim3(256), 0, s, (const T*)dy, (const T*)x,
+                       (const T*)y, (T*)dx, (T*)dres, nchunks, cc, C, coef, relu);
+  };
+  auto go2 = [&](auto rmc, auto dresc) { nt ? go(rmc, dresc, std::true_type{}) : go(rmc, dresc, std::false_type{}); };
+  auto go1 = [&](auto rmc) { dres != nullptr ? go2(rmc, std::true_type{}) : go2(rmc, std::false_type{}); };
+  switch (relu & 3) {
+    case 0: go1(std::integral_constant<int, 0>{}); break;
+    case 1: go1(std::integral_constant<int, 1>{}); break;
+    case 2: go1(std::integral_constant<int, 2>{}); break;
+    default: go1(std::integral_constant<int, 3>{}); break;
+  }
+}
+
 inline int grid_for(long nchunks) {
   long b = (nchunks + 255) / 256;
   if (b > g_bn_grid) b = g_bn_grid;
@@ -696,6 +893,28 @@ inline int grid_for(long nchunks) {
 void check_c(int C, int dtype) {
   const int vec = dtype == kF32 ? 4 : 8;
   if (C % vec != 0) throw std::invalid_argument("bn: C must be a multiple of 16 bytes");
+}
+
+template <typename T, int MODE, bool SMOOTH>
+void col_reduce_t(dim3 grid, hipStream_t s, const void* a, const void* x, const void* y, long M, int C, const float* mean,
+                  const float* invstd, int relu, const float* scale, const float* shift, float* partial, long rpb) {
+  auto go = [&](auto rmc, auto ntc) {
+    hipLaunchKernelGGL((col_reduce_kernel<T, MODE, SMOOTH, decltype(rmc)::value, decltype(ntc)::value>), grid,
+                       dim3(kBnThreads), 0, s, (const T*)a, (const T*)x, (const T*)y, M, C, mean, invstd, relu, scale,
+                       shift, partial, rpb);
+  };
+  using std::integral_constant;
+  if constexpr (MODE == 0) {
+    go(integral_constant<int, 0>{}, std::false_type{});
+  } else {
+    const bool nt = (relu & 256) != 0;
+    switch (relu & 3) {
+      case 0: nt ? go(integral_constant<int, 0>{}, std::true_type{}) : go(integral_constant<int, 0>{}, std::false_type{}); break;
+      case 1: nt ? go(integral_constant<int, 1>{}, std::true_type{}) : go(integral_constant<int, 1>{}, std::false_type{}); break;
+      case 2: nt ? go(integral_constant<int, 2>{}, std::true_type{}) : go(integral_constant<int, 2>{}, std::false_type{}); break;
+      default: nt ? go(integral_constant<int, 3>{}, std::true_type{}) : go(integral_constant<int, 3>{}, std::false_type{}); break;
+    }
+  }
 }
 
 template <int MODE>
@@ -709,21 +928,13 @@ void col_reduce(const void* a, const void* x, const void* y, long M, int C, int 
   dim3 grid(nblk, gy);
   if (MODE == 1 && ((relu >> 4) & 7) != 0) {
     if (scale == nullptr || shift == nullptr) throw std::invalid_argument("bn: a fused activation needs scale / shift");
-    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col_reduce_kernel<T, MODE, MODE == 1>), grid, dim3(kBnThreads), 0, s,
-                                                 (const T*)a, (const T*)x, (const T*)y, M, C, mean, invstd, relu, scale,
-                                                 shift, partial, rpb));
+    DPA_DISPATCH_DTYPE(dtype, (col_reduce_t<T, MODE, MODE == 1>(grid, s, a, x, y, M, C, mean, invstd, relu, scale, shift,
+                                                                partial, rpb)));
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
-  if (dtype == kF32)
-    hipLaunchKernelGGL((col_reduce_kernel<float, MODE>), grid, dim3(kBnThreads), 0, s, (const float*)a,
-                       (const float*)x, (const float*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
-  else if (dtype == kBF16)
-    hipLaunchKernelGGL((col_reduce_kernel<bf16_t, MODE>), grid, dim3(kBnThreads), 0, s, (const bf16_t*)a,
-                       (const bf16_t*)x, (const bf16_t*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
-  else
-    hipLaunchKernelGGL((col_reduce_kernel<f16_t, MODE>), grid, dim3(kBnThreads), 0, s, (const f16_t*)a,
-                       (const f16_t*)x, (const f16_t*)y, M, C, mean, invstd, relu, scale, shift, partial, rpb);
+  DPA_DISPATCH_DTYPE(dtype, (col_reduce_t<T, MODE, false>(grid, s, a, x, y, M, C, mean, invstd, relu, scale, shift,
+                                                          partial, rpb)));
   DPA_CHECK_HIP(hipGetLastError());
 }
 
@@ -803,6 +1014,12 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
+  if ((g_bn_reverse & (13 | 128)) == 0 && ((long)grid * 256) % (C / vec) == 0) {
+    DPA_DISPATCH_DTYPE(dtype, (bn_apply_fast<T>(grid, s, x, residual, y, nchunks, C / vec, scale, shift, relu, mask,
+                                                res_scale, res_shift, nt)));
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
   if (g_bn_unroll >= 4) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(grid), dim3(256), 0, s, (const T*)x,
                                                  (const T*)residual, (T*)y, nchunks, C / vec, scale, shift, relu, (g_bn_reverse & 1) | (nt ? 6 : ((g_bn_reverse >> 2) & 3) << 1), mask, res_scale, res_shift));
@@ -844,6 +1061,12 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                  (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C, coef,
                                                  relu, ((g_bn_reverse >> 1) & 1) | (nt_auto(nchunks * 16, 2) ? 6 : 0)));
+    DPA_CHECK_HIP(hipGetLastError());
+    return;
+  }
+  if ((g_bn_reverse & (50 | 128)) == 0 && ((long)grid * 256) % (C / vec) == 0) {
+    DPA_DISPATCH_DTYPE(dtype, (bn_bwd_apply_fast<T>(grid, s, dy, x, y, dx, dres, nchunks, C / vec, C, coef, relu,
+                                                    nt_auto(nchunks * 16, 2))));
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
@@ -909,11 +1132,12 @@ void bn_bwd_fold_finalize_launch(const float* partial, int nparts, int C, double
 }
 
 void bn_set_tuning(int grid_blocks, int unroll) {
-  g_bn_grid = grid_blocks > 0 ? grid_blocks : 256 * 8;
+  g_bn_grid = grid_blocks > 0 ? grid_blocks : 256 * 5;
   g_bn_unroll = unroll > 0 ? unroll : 1;
 }
 // bit 0: forward apply walks from the end, bit 1: backward apply does; bits 2-3: forward apply streaming stores /
-// loads; bits 4-5: backward apply streaming stores / loads; bit 6: backward reduce streaming loads (nontemporal)
+// loads; bits 4-5: backward apply streaming stores / loads; bit 6: backward reduce streaming loads (nontemporal);
+// bit 7: generic apply kernels only (A/B against the lean streaming variants)
 void bn_set_reverse(int mask) { g_bn_reverse = mask; }
 void set_nt_min_bytes(long bytes) { g_nt_min_bytes = bytes; }
 long nt_min_bytes() { return (g_nt_mask & 8) ? g_nt_min_bytes : -1; }
