@@ -76,6 +76,7 @@ PYBIND11_MODULE(_C, m) {
   m.def("igemm_set_nt_store", &igemm_set_nt_store);
   m.def("set_nt_min_bytes", &set_nt_min_bytes);
   m.def("set_nt_mask", &set_nt_mask);
+  m.def("set_stream_grid", &set_stream_grid);
   m.def("igemm_tile_m", &igemm_tile_m);
   m.def("igemm_stats_rows", &igemm_stats_rows);
   m.def("igemm_force_config", &igemm_force_config);

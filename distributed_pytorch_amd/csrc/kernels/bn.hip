@@ -884,10 +884,22 @@ void bn_bwd_apply_fast(int grid, hipStream_t s, const void* dy, const void* x, c
   }
 }
 
-inline int grid_for(long nchunks) {
+// Workgroups for a grid-stride pass over `nchunks` 16-byte chunks of a [rows][cc chunks] tensor: at most g_bn_grid, and
+// -- when the tensor takes more than one trip -- a multiple of cc / gcd(cc, 256), so that the grid stride is a multiple
+// of the chunk-column count and a thread keeps ONE channel chunk (coefficients in registers, the lean kernels) for any
+// channel count, not only powers of two (DenseNet's 64 + 32k, EfficientNet's 144 / 240 / 672 ...).
+inline int grid_for(long nchunks, int cc = 0) {
   long b = (nchunks + 255) / 256;
-  if (b > g_bn_grid) b = g_bn_grid;
-  return (int)(b < 1 ? 1 : b);
+  if (b <= g_bn_grid) return (int)(b < 1 ? 1 : b);
+  b = g_bn_grid;
+  if (cc > 0) {
+    int a = cc, g = 256;
+    while (g) { const int t = a % g; a = g; g = t; }     // a = gcd(cc, 256)
+    const long m = cc / a;
+    if (m <= b) b = b / m * m;
+    else if (m <= 2 * b) b = m;
+  }
+  return (int)b;
 }
 
 void check_c(int C, int dtype) {
@@ -1004,7 +1016,7 @@ void bn_apply_launch(const void* x, const void* residual, void* y, long M, int C
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
-  const int grid = grid_for(nchunks);
+  const int grid = grid_for(nchunks, C / vec);
   const bool nt = nt_auto(nchunks * 16, 1);
   if (((relu >> 4) & 7) != 0) {        // BN + smooth activation (SiLU, hard-swish, ...) in one pass
     if (mask != nullptr) throw std::invalid_argument("bn_apply: no bit mask with a smooth activation");
@@ -1056,7 +1068,7 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
   const int vec = dtype == kF32 ? 4 : 8;
   const long nchunks = M * (C / vec);
   if (nchunks <= 0) return;
-  const int grid = grid_for(nchunks);
+  const int grid = grid_for(nchunks, C / vec);
   if (((relu >> 4) & 7) != 0) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)dy,
                                                  (const T*)x, (const T*)y, (T*)dx, (T*)dres, nchunks, C / vec, C, coef,

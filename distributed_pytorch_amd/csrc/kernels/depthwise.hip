@@ -286,7 +286,7 @@ int dw_conv_rows(long npix, int C, int dtype) {
   const int CSL = slab_lanes(chunks);
   const int gy = ceil_div(chunks, CSL);
   long bx = ceil_div(npix, (long)(256 / CSL));
-  const long cap = std::max(1, 2048 / gy);
+  const long cap = std::max(1, (g_stream_grid / 2) / gy);
   if (bx > cap) bx = cap;
   return (int)(bx < 1 ? 1 : bx);
 }

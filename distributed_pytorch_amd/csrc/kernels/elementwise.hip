@@ -10,7 +10,7 @@ namespace {
 
 inline int grid_for(long n, int per_block = 256) {
   long b = (n + per_block - 1) / per_block;
-  if (b > 256 * 16) b = 256 * 16;
+  if (b > g_stream_grid) b = g_stream_grid;
   return (int)(b < 1 ? 1 : b);
 }
 
@@ -560,5 +560,8 @@ void shuffle_pair_launch(const void* a, const void* b, void* o0, void* o1, long 
 void fill_launch(void* p, long nbytes, int value, hipStream_t s) {
   if (nbytes > 0) DPA_CHECK_HIP(hipMemsetAsync(p, value, (size_t)nbytes, s));
 }
+
+int g_stream_grid = 256 * 16;     // measured 1280 / 2560 / 4096 / 5120 on seven families: 4096 best or equal (profiles/r2/stream_grid_ab.txt)
+void set_stream_grid(int blocks) { g_stream_grid = blocks > 0 ? blocks : 256 * 16; }
 
 }  // namespace dpa

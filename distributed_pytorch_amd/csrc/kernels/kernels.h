@@ -72,6 +72,9 @@ void igemm_set_nt_store(int mode);  // streaming (nontemporal) stores of the out
 // tensors of at least this many bytes are streamed with nontemporal loads / stores (negative: never)
 void set_nt_min_bytes(long bytes);
 long nt_min_bytes();
+// Workgroup cap of the grid-stride streaming kernels (elementwise, pooling, depthwise).  Not a power of two: see bn.hip.
+extern int g_stream_grid;
+void set_stream_grid(int blocks);
 void set_nt_mask(int mask);   // 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm output stores
 int igemm_num_configs();
 

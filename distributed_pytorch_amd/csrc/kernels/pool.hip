@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict
 
 inline int grid_for(long n) {
   long b = (n + 255) / 256;
-  if (b > 256 * 16) b = 256 * 16;
+  if (b > g_stream_grid) b = g_stream_grid;
   return (int)(b < 1 ? 1 : b);
 }
 // a pixel lies in at most 2 windows per axis (3x3 s2, 2x2 s2, 3x3 s2 ceil ...): the gather's fast path
@@ -556,7 +556,7 @@ FusedGeom fused_geom(int NB, int IH, int IW, int C, int OH, int OW, int kh, int 
 
 int bn_relu_maxpool_partial_rows(long in_chunks) {
   long b = (in_chunks + 256 * 8 - 1) / (256 * 8);     // >= 8 chunks per thread
-  if (b > 2048) b = 2048;
+  if (b > g_stream_grid / 2) b = g_stream_grid / 2;
   return (int)(b < 1 ? 1 : b);
 }
 
