@@ -301,6 +301,9 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 // bn_bwd_finalize_fused (backward): 2 of the 4 tiny launches per BatchNorm layer and direction.
 // MODE 0: forward statistics -> mean, invstd, scale, shift (+ running stats).  MODE 1: backward sums ->
 // dgamma, dbeta, apply coefficients [5][C].
+#ifndef DPA_BN_FOLD_ROWS
+#define DPA_BN_FOLD_ROWS 256
+#endif
 struct BnFinalizeArgs {
   const float* partial; int nparts, C, chunk, nchunk;
   double* tmp; int* counter;
@@ -327,9 +330,8 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
   const float* __restrict__ cnt = a.partial + (size_t)a.nparts * 2 * C;
   float inv_n_of = -1.f;       // the parts of a slab have the same row count except the last: one division, reused
   double inv_n = 0.0;
-  auto second = [&](int k, float sum_k, float b_k) -> double {
+  auto second = [&](float nk, float sum_k, float b_k) -> double {
     if (MODE == 1) return (double)b_k;
-    const float nk = cnt[k];
     if (nk != inv_n_of) {
       inv_n_of = nk;
       inv_n = nk > 0.f ? 1.0 / (double)nk : 0.0;
@@ -339,18 +341,25 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int k = p0 + pl;
-    for (; k + 12 < p1; k += 16) {          // 4 independent row pairs in flight per lane
-      const float a0 = a.partial[((size_t)k * 2 + 0) * C + c], b0 = a.partial[((size_t)k * 2 + 1) * C + c];
-      const float a1 = a.partial[((size_t)(k + 4) * 2 + 0) * C + c], b1 = a.partial[((size_t)(k + 4) * 2 + 1) * C + c];
-      const float a2 = a.partial[((size_t)(k + 8) * 2 + 0) * C + c], b2 = a.partial[((size_t)(k + 8) * 2 + 1) * C + c];
-      const float a3 = a.partial[((size_t)(k + 12) * 2 + 0) * C + c], b3 = a.partial[((size_t)(k + 12) * 2 + 1) * C + c];
-      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      s2 += (second(k, a0, b0) + second(k + 4, a1, b1)) + (second(k + 8, a2, b2) + second(k + 12, a3, b3));
+    for (; k + 28 < p1; k += 32) {          // 8 independent row pairs in flight per lane
+      float av[8], bv[8], nv[8];         // the row counts ride with the batch (a load inside second() is a dependent trip)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        av[u] = a.partial[((size_t)(k + 4 * u) * 2 + 0) * C + c];
+        bv[u] = a.partial[((size_t)(k + 4 * u) * 2 + 1) * C + c];
+        nv[u] = MODE == 1 ? 0.f : cnt[k + 4 * u];
+      }
+      s1 += (((double)av[0] + (double)av[1]) + ((double)av[2] + (double)av[3])) +
+            (((double)av[4] + (double)av[5]) + ((double)av[6] + (double)av[7]));
+      s2 += ((second(nv[0], av[0], bv[0]) + second(nv[1], av[1], bv[1])) +
+             (second(nv[2], av[2], bv[2]) + second(nv[3], av[3], bv[3]))) +
+            ((second(nv[4], av[4], bv[4]) + second(nv[5], av[5], bv[5])) +
+             (second(nv[6], av[6], bv[6]) + second(nv[7], av[7], bv[7])));
     }
     for (; k < p1; k += 4) {
       const float a0 = a.partial[((size_t)k * 2 + 0) * C + c], b0 = a.partial[((size_t)k * 2 + 1) * C + c];
       s1 += (double)a0;
-      s2 += second(k, a0, b0);
+      s2 += second(MODE == 1 ? 0.f : cnt[k], a0, b0);
     }
   }
   red[0][pl][cl] = s1;
@@ -380,13 +389,15 @@ __global__ __launch_bounds__(256) void bn_fold_finalize_kernel(const BnFinalizeA
     s1 = s2 = 0.0;
     if (c < C) {
       int k = pl;
-      for (; k + 12 < a.nchunk; k += 16) {
-        const double a0 = a.tmp[((size_t)k * 2 + 0) * C + c], b0 = a.tmp[((size_t)k * 2 + 1) * C + c];
-        const double a1 = a.tmp[((size_t)(k + 4) * 2 + 0) * C + c], b1 = a.tmp[((size_t)(k + 4) * 2 + 1) * C + c];
-        const double a2 = a.tmp[((size_t)(k + 8) * 2 + 0) * C + c], b2 = a.tmp[((size_t)(k + 8) * 2 + 1) * C + c];
-        const double a3 = a.tmp[((size_t)(k + 12) * 2 + 0) * C + c], b3 = a.tmp[((size_t)(k + 12) * 2 + 1) * C + c];
-        s1 += (a0 + a1) + (a2 + a3);
-        s2 += (b0 + b1) + (b2 + b3);
+      for (; k + 28 < a.nchunk; k += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          av[u] = a.tmp[((size_t)(k + 4 * u) * 2 + 0) * C + c];
+          bv[u] = a.tmp[((size_t)(k + 4 * u) * 2 + 1) * C + c];
+        }
+        s1 += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+        s2 += ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + (bv[6] + bv[7]));
       }
       for (; k < a.nchunk; k += 4) {
         s1 += a.tmp[((size_t)k * 2 + 0) * C + c];
@@ -1090,10 +1101,12 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
 
 // Rows of the scratch slab bn_fold_finalize needs for `nparts` partial rows (1 = no scratch pass).
 int bn_fold_chunks(int nparts) {
-  // The fold is latency bound: 64 rows per workgroup = ONE trip of 16 rows per lane with every load in flight.
-  // (Batch-1024 slabs have 25k rows; at 32 chunks a lane walked 196 rows in 12 dependent trips: 27 us per layer.)
+  // The fold is latency bound: a lane keeps 8 row pairs in flight per trip, in both phases.  DPA_BN_FOLD_ROWS rows per
+  // workgroup balance the trips of the first phase (rows / 32) against the last arriver's (chunks / 32): a batch-1024
+  // slab has 25k rows -> 256 rows per workgroup = 8 + 3 trips (64 rows, 4 pairs in flight: 4 + 25 trips, 20 us per layer).
   if (nparts <= 64) return 1;
-  int n = (nparts + 63) / 64;
+  int n = (nparts + DPA_BN_FOLD_ROWS - 1) / DPA_BN_FOLD_ROWS;
+  if (n < 2) n = 2;
   return n > 512 ? 512 : n;
 }
 
