@@ -120,12 +120,14 @@ __global__ __launch_bounds__(kBnThreads, 4) void col_reduce_kernel(const T* __re
   };
   if (active) {
     long r = r_begin + rl;
-    // 4 rows per trip, every load issued before the first use (the summation order stays fixed)
-    for (; r + 3 * rp < r_end; r += 4 * rp) {
-      Vec16<T> va[4], vx[MODE == 1 ? 4 : 1], vy[MODE == 1 && rm == 1 ? 4 : 1];
-      uint32_t mb[4] = {0, 0, 0, 0};
+    // UR rows per trip, every load issued before the first use (the summation order stays fixed); the smooth-activation
+    // variants evaluate an exp + rcp per element and spill at 4 rows under the 128-VGPR cap: 2 rows there
+    constexpr int UR = SMOOTH ? 2 : 4;
+    for (; r + (UR - 1) * rp < r_end; r += UR * rp) {
+      Vec16<T> va[UR], vx[MODE == 1 ? UR : 1], vy[MODE == 1 && rm == 1 ? UR : 1];
+      uint32_t mb[UR] = {};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UR; ++u) {
         const size_t off = (size_t)(r + u * rp) * C + c0;
         if constexpr (MODE == 1 && rm == 3) mb[u] = reinterpret_cast<const uint8_t*>(y)[off / VEC];
         if constexpr (ntl) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(kBnThreads, 4) void col_reduce_kernel(const T* __re
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) accumulate(va[u], vx[MODE == 1 ? u : 0], vy[MODE == 1 && rm == 1 ? u : 0], mb[u]);
+      for (int u = 0; u < UR; ++u) accumulate(va[u], vx[MODE == 1 ? u : 0], vy[MODE == 1 && rm == 1 ? u : 0], mb[u]);
     }
     for (; r < r_end; r += rp) {
       const size_t off = (size_t)r * C + c0;
