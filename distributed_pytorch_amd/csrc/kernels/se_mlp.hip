@@ -121,49 +121,73 @@ __global__ __launch_bounds__(kSeThreads) void se_cols_kernel(const float* __rest
     }
 }
 
-// Parameter gradients: one thread per output element, a fixed-order loop over the batch (deterministic), eight loads
-// in flight per thread.
+// Parameter gradients: an output element is owned by 8 lanes that each walk one eighth of the batch with eight loads in
+// flight and meet in LDS in a fixed order (deterministic).  (One thread per element walking the whole batch four loads
+// at a time was 64 dependent trips on 150 workgroups: 83 us per SE block on EfficientNet-B0.)
 //   [0, S*C)            dW1[j][c] = sum_n dz1[n][j] p[n][c]
 //   [S*C, 2*S*C)        dW2[c][j] = sum_n dz2[n][c] h[n][j]
 //   then db1[S], db2[C]
 __device__ __forceinline__ float se_dot_n(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb, int N) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
   int n = 0;
-  for (; n + 3 < N; n += 4) {
-    a0 += a[(long)n * lda] * b[(long)n * ldb];
-    a1 += a[(long)(n + 1) * lda] * b[(long)(n + 1) * ldb];
-    a2 += a[(long)(n + 2) * lda] * b[(long)(n + 2) * ldb];
-    a3 += a[(long)(n + 3) * lda] * b[(long)(n + 3) * ldb];
+  for (; n + 7 < N; n += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += a[(long)(n + u) * lda] * b[(long)(n + u) * ldb];
   }
-  for (; n < N; ++n) a0 += a[(long)n * lda] * b[(long)n * ldb];
-  return (a0 + a1) + (a2 + a3);
+  for (; n < N; ++n) acc[0] += a[(long)n * lda] * b[(long)n * ldb];
+  return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
+__device__ __forceinline__ float se_sum_n(const float* __restrict__ a, long lda, int N) {
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  int n = 0;
+  for (; n + 7 < N; n += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += a[(long)(n + u) * lda];
+  }
+  for (; n < N; ++n) acc[0] += a[(long)n * lda];
+  return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
+constexpr int kSeWgOut = 32;       // outputs per workgroup (x 8 batch slices = 256 threads)
 
 __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restrict__ dz1, const float* __restrict__ dz2,
                                                            const float* __restrict__ p, const float* __restrict__ h,
                                                            float* __restrict__ dw1, float* __restrict__ db1,
                                                            float* __restrict__ dw2, float* __restrict__ db2, int N, int C,
                                                            int S) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[8][kSeWgOut];
+  const int ol = threadIdx.x & (kSeWgOut - 1), sl = threadIdx.x / kSeWgOut;
+  const long i = (long)blockIdx.x * kSeWgOut + ol;
   const long sc = (long)S * C;
+  const int n0 = (int)((long)N * sl / 8), nn = (int)((long)N * (sl + 1) / 8) - n0;
+  float v = 0.f;
+  float* out = nullptr;
   if (i < sc) {
     const int j = (int)(i / C), c = (int)(i - (long)j * C);
-    dw1[i] = se_dot_n(dz1 + j, S, p + c, C, N);
+    v = se_dot_n(dz1 + (long)n0 * S + j, S, p + (long)n0 * C + c, C, nn);
+    out = dw1 + i;
   } else if (i < 2 * sc) {
     const long k = i - sc;
     const int c = (int)(k / S), j = (int)(k - (long)c * S);
-    dw2[k] = se_dot_n(dz2 + c, C, h + j, S, N);
+    v = se_dot_n(dz2 + (long)n0 * C + c, C, h + (long)n0 * S + j, S, nn);
+    out = dw2 + k;
   } else if (i < 2 * sc + S) {
     const int j = (int)(i - 2 * sc);
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += dz1[(long)n * S + j];
-    db1[j] = a;
+    v = se_sum_n(dz1 + (long)n0 * S + j, S, nn);
+    out = db1 + j;
   } else if (i < 2 * sc + S + C) {
     const int c = (int)(i - 2 * sc - S);
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += dz2[(long)n * C + c];
-    db2[c] = a;
+    v = se_sum_n(dz2 + (long)n0 * C + c, C, nn);
+    out = db2 + c;
   }
+  red[sl][ol] = v;
+  __syncthreads();
+  if (sl == 0 && out != nullptr)
+    *out = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
 }
 
 void se_check(int N, int C, int S) {
@@ -208,7 +232,7 @@ void se_mlp_bwd_launch(const float* ds, const float* s, const float* z2, const f
                      w1, nullptr, dp, nullptr, N, C, S, gate, inv_hw);
   if (dw1 != nullptr) {
     const long total = 2l * S * C + S + C;
-    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dz1, dz2, p, h, dw1,
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((unsigned)((total + kSeWgOut - 1) / kSeWgOut)), dim3(256), 0, st, dz1, dz2, p, h, dw1,
                        db1, dw2, db2, N, C, S);
   }
   DPA_CHECK_HIP(hipGetLastError());
