@@ -282,6 +282,7 @@ PYBIND11_MODULE(_C, m) {
     relu_bwd_launch(ptr<const void>(y), ptr<const void>(dy), ptr<void>(dx), n, dtype, st(s));
   });
   m.def("dw_conv_rows", &dw_conv_rows);
+  m.def("dw_set_sliding", &dw_set_sliding);
   m.def("dw_wgrad_rows", &dw_wgrad_rows);
   m.def("dw_conv", [](uintptr_t in, uintptr_t w, int w_dtype, uintptr_t bias, uintptr_t out, uintptr_t stats, int backward,
                       int NB, int IH, int IW, int C, int OH, int OW, int KH, int KW, int sh, int sw, int ph, int pw,

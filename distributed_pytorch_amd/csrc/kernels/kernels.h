@@ -208,6 +208,7 @@ void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
 void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
 // direct depthwise convolution (groups == channels); w = the parameter's memory [C][KH][KW] (fp32 or compute dtype)
+void dw_set_sliding(int on);    // 0: window-per-pixel depthwise kernels only
 int dw_conv_rows(long npix, int C, int dtype);
 void dw_conv_launch(const void* in, const void* w, int w_dtype, const float* bias, void* out, float* stats, int backward,
                     int NB, int IH, int IW, int C, int OH, int OW, int KH, int KW, int sh, int sw, int ph, int pw, int relu,

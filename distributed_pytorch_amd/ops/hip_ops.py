@@ -39,6 +39,8 @@ def C():
         _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
         if "DPA_BN_GRID" in os.environ:          # workgroups of the BN streaming passes (default 1280, see bn.hip)
             _C.bn_set_tuning(int(os.environ["DPA_BN_GRID"]), 1)
+        if "DPA_DW_SLIDING" in os.environ:       # 0: window-per-pixel depthwise kernels only
+            _C.dw_set_sliding(int(os.environ["DPA_DW_SLIDING"]))
         if "DPA_STREAM_GRID" in os.environ:      # workgroup cap of the elementwise / pooling / depthwise kernels
             _C.set_stream_grid(int(os.environ["DPA_STREAM_GRID"]))
         if "DPA_NT_MASK" in os.environ:          # 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm stores
