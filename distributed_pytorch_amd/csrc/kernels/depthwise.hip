@@ -733,7 +733,7 @@ void check_geom(const DwGeom& g, int dtype) {
 
 }  // namespace
 
-int g_dw_s1 = 1;       // 0: never the sliding-window kernel (A/B hook, dw_set_sliding)
+int g_dw_s1 = 1;       // 0: never the sliding-window / 2x2-block kernels (A/B hook, dw_set_sliding); >= 2: strip height
 void dw_set_sliding(int on) { g_dw_s1 = on; }
 
 int dw_conv_rows(long npix, int C, int dtype) {
@@ -782,8 +782,11 @@ void dw_conv_launch(const void* in, const void* w, int w_dtype, const float* bia
   if (g_dw_s1 && dtype != kF32 && sh == 1 && sw == 1 && KH == KW && (KH == 3 || KH == 5) && ph < KH && pw < KW) {
     // sliding-window kernel: strips of R rows; shorter strips when the problem has few columns to hand out
     const int PH = backward ? IH : OH, PW = backward ? IW : OW;
+    // rows per strip: 8 unless that leaves fewer columns than ~4 workgroups per CU have lanes for (workgroups beyond
+    // the columns idle and write empty statistics rows); g_dw_s1 >= 2 forces the strip height (tests)
     int R = 8;
-    while (R > 2 && (long)NB * ceil_div(PH, R) * PW < (long)grid.x * (256 / CSL) * 2) R >>= 1;
+    while (R > 1 && (long)NB * ceil_div(PH, R) * PW * (long)grid.y < 1024l * (256 / CSL)) R >>= 1;
+    if (g_dw_s1 >= 2) R = g_dw_s1;
     const int nstrips = ceil_div(PH, R);
     if ((long)NB * nstrips * PW >= (1L << 31)) throw std::invalid_argument("depthwise: more than 2^31 columns");
     const FastDiv dvw = make_fastdiv((uint32_t)PW), dvs = make_fastdiv((uint32_t)nstrips);

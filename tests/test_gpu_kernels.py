@@ -26,7 +26,8 @@ def _slab_m2(stats):
     tiles = stats.shape[0]
     cnt = stats.flatten().as_strided((tiles,), (1,), stats.numel()).double()
     s, m2 = stats[:, 0].double(), stats[:, 1].double()
-    return (m2.sum(0) + (s * s / cnt[:, None]).sum(0) - s.sum(0) ** 2 / cnt.sum()).float()
+    part = torch.where(cnt[:, None] > 0, s * s / cnt[:, None].clamp(min=1.0), torch.zeros_like(s))   # empty parts: 0 rows
+    return (m2.sum(0) + part.sum(0) - s.sum(0) ** 2 / cnt.sum()).float()
 
 
 CONV_CASES = [
@@ -576,6 +577,10 @@ GROUP_CASES = [
     (3, 9, 9, 8, 8, 8, 3, 1, 1),            # a single 16-byte chunk
     (2, 28, 28, 144, 144, 144, 3, 2, 1),    # two channel slabs, ragged second one
     (130, 5, 5, 24, 24, 24, 3, 1, 1),       # many images, tiny extent
+    (2, 14, 14, 240, 240, 240, 5, 1, 2),    # sliding-window kernel, 5x5 stride 1 (EfficientNet), 30 chunks -> slabs of 15
+    (3, 30, 20, 16, 16, 16, 3, 1, 1),       # sliding-window kernel over several strips, last one ragged
+    (2, 12, 16, 24, 24, 24, 5, 1, 1),       # 5x5 with padding 1 (output smaller than the input)
+    (2, 16, 12, 32, 32, 32, 3, 2, 1),       # stride-2 backward-data on 2x2 blocks, non-square
 ]
 
 
@@ -611,6 +616,38 @@ def test_group_conv_fwd_bwd(case, dtype, bias_relu):
     _close(w.grad, wr.grad, dtype, what="wgrad")
     if b is not None:
         _close(b.grad, br.grad, dtype, what="bias grad")
+
+
+@pytest.mark.parametrize("rows", [0, 3, 8])
+@pytest.mark.parametrize("k", [3, 5])
+def test_depthwise_sliding_window_strip_heights(k, rows):
+    """The stride-1 sliding-window depthwise kernels (forward + backward-data) at forced strip heights -- 3 leaves a
+    ragged last strip and a window rotation that ends mid-period, 8 is the production height -- against the
+    window-per-pixel kernels (rows = 0) and fp32 autograd."""
+    from distributed_pytorch_amd.ops import hip_ops
+
+    torch.manual_seed(9)
+    N, H, W, Cc = 3, 19, 13, 48
+    x0 = torch.randn(N, H, W, Cc, device=DEV).to(torch.bfloat16)
+    w0 = (torch.randn(Cc, 1, k, k, device=DEV) / k).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, H, W, Cc, device=DEV).to(torch.bfloat16)
+    hip_ops.C().dw_set_sliding(rows)
+    try:
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        y, stats = F.conv2d(x, w, None, 1, k // 2, groups=Cc, want_stats=True)
+        y.backward(gy)
+    finally:
+        hip_ops.C().dw_set_sliding(1)
+    xr = x0.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w0.to(torch.bfloat16).float().requires_grad_(True)
+    yr = TF.conv2d(xr, wr, None, 1, k // 2, 1, Cc)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2), yr, torch.bfloat16, what="fprop")
+    yf = y.detach().float().reshape(-1, Cc)
+    _close(stats.sum(0)[0], yf.sum(0), torch.float32, scale=10, what="stats sum")
+    _close(_slab_m2(stats), (yf - yf.mean(0)).square().sum(0), torch.float32, scale=10, what="stats M2")
+    _close(x.grad.permute(0, 3, 1, 2), xr.grad, torch.bfloat16, what="dgrad")
+    _close(w.grad, wr.grad, torch.bfloat16, what="wgrad")
 
 
 def test_depthwise_direct_equals_block_diagonal_path():
