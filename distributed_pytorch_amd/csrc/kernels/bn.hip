@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
       }
       if constexpr (SMOOTH) d *= act_slope((relu >> 4) & 7, sc[j] * xv + sh[j]);
-      vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
+      vo.set(j, fmaf(ca[j], d, fmaf(cb[j], xv, ck[j])));      // explicit: every instantiation contracts alike
       vr.set(j, d);
     }
     if (nts) vo.store_nt(dx + q * VEC);
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256, DPA_BN_OCC) void bn_bwd_apply_fast_kernel(
         const float yv = to_float(from_float<T>(sc[j] * xv + sh[j]));
         if (!(yv > 0.f) || (clip && !(yv < 6.f))) d = 0.f;
       }
-      vo.set(j, ca[j] * d + cb[j] * xv + ck[j]);
+      vo.set(j, fmaf(ca[j], d, fmaf(cb[j], xv, ck[j])));      // explicit: every instantiation contracts alike
       if constexpr (DRES) vr.set(j, d);
     }
     if constexpr (NT) vo.store_nt(dx + q * VEC);
