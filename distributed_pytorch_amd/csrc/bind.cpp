@@ -281,6 +281,11 @@ PYBIND11_MODULE(_C, m) {
   m.def("relu_bwd", [](uintptr_t y, uintptr_t dy, uintptr_t dx, long n, int dtype, uintptr_t s) {
     relu_bwd_launch(ptr<const void>(y), ptr<const void>(dy), ptr<void>(dx), n, dtype, st(s));
   });
+  m.def("gemm8", [](uintptr_t A, uintptr_t B, uintptr_t Cc, uintptr_t bias, int M, int N, int K, long lda, long ldb, long ldc,
+                    int relu, int dtype, uintptr_t s) {
+    gemm8_launch(ptr<const void>(A), ptr<const void>(B), ptr<void>(Cc), ptr<const float>(bias), M, N, K, lda, ldb, ldc, relu,
+                 dtype, st(s));
+  });
   m.def("dw_conv_rows", &dw_conv_rows);
   m.def("dw_set_sliding", &dw_set_sliding);
   m.def("dw_wgrad_rows", &dw_wgrad_rows);

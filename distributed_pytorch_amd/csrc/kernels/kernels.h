@@ -208,6 +208,9 @@ void relu_fwd_launch(const void* x, void* y, long n, int dtype, hipStream_t s);
 void relu_bwd_launch(const void* y, const void* dy, void* dx, long n, int dtype, hipStream_t s);
 void add_relu_fwd_launch(const void* a, const void* b, void* y, long n, int dtype, hipStream_t s);
 // direct depthwise convolution (groups == channels); w = the parameter's memory [C][KH][KW] (fp32 or compute dtype)
+// 256 x 256 multi-phase GEMM (gemm8.hip): C[M][N] = A[M][K] * B[N][K]^T (+ bias) (+ ReLU); 16-bit, K % 64 == 0, N % 8 == 0
+void gemm8_launch(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
+                  long ldc, int relu, int dtype, hipStream_t stream);
 void dw_set_sliding(int on);    // 0: window-per-pixel depthwise kernels only
 int dw_conv_rows(long npix, int C, int dtype);
 void dw_conv_launch(const void* in, const void* w, int w_dtype, const float* bias, void* out, float* stats, int backward,

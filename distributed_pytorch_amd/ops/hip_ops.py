@@ -2072,6 +2072,34 @@ def _padded_rows(t: torch.Tensor, n: int, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+_GEMM8 = int(os.environ.get("DPA_GEMM8", "1"))      # 256x256 multi-phase GEMM: 1 by shape, 0 never, 2 whenever legal
+
+
+def _gemm8_wins(M: int, N: int, K: int, dtype, out_dtype) -> bool:
+    """The 256x256 multi-phase kernel (csrc/kernels/gemm8.hip) against the lean 128-row GEMM, measured on one MI355X
+    (scratch/gemm8_check.py -> profiles/r2/gemm8_vs_lean.txt): it needs a long K loop to amortise its pipeline fill
+    (1.1 PFLOP/s at 4096^3, 870 vs 708 TFLOP/s at 25216 x 3072 x 768) and a tile count that fills whole rounds of
+    the 256 CUs (25216 x 768: 296 tiles = 2 rounds at 58 % -> the lean kernel wins there)."""
+    if _GEMM8 == 0 or dtype == torch.float32 or out_dtype != dtype or K % 64 or N % 8:
+        return False
+    if _GEMM8 >= 2:
+        return True
+    tiles = -(-M // 256) * -(-N // 256)
+    rounds = -(-tiles // 256)
+    return K >= 768 and tiles >= 256 and tiles / (rounds * 256.0) >= 0.85
+
+
+def _plain_gemm(A, B, Cbuf, bias_f, M, N, K, lda, ldb, ldc, relu, dtype, out_dtype):
+    """Cbuf[M, N] = A[M, K] @ B[N, K]^T (+ bias) (+ ReLU): the multi-phase kernel where it wins, else the lean GEMM."""
+    if _gemm8_wins(M, N, K, dtype, out_dtype) and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0:
+        C().gemm8(A.data_ptr(), B.data_ptr(), Cbuf.data_ptr(), _p(bias_f), M, N, K, lda, ldb, ldc, int(bool(relu)),
+                  _dt(dtype), _stream())
+        return
+    taps = _tap_table(A.device, _ONE_TAP)
+    _igemm(A, B, Cbuf, bias_f, None, taps, M, N, K, 1, lda, ldb, ldc, 1, 1, 1, 1, 1, 1, relu=relu, dtype=dtype,
+           out_dtype=out_dtype)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu, out_dtype):
@@ -2086,10 +2114,8 @@ class _LinearFn(torch.autograd.Function):
         odt = out_dtype or x2.dtype
         ldc = _round_up(out_f, 8)
         buf = torch.empty((M, ldc), dtype=odt, device=x.device)
-        taps = _tap_table(x.device, _ONE_TAP)
         bias_f = None if bias is None else _f32(bias.detach())
-        _igemm(x2, wc, buf, bias_f, None, taps, M, out_f, in_f, 1, in_f, in_f, ldc, 1, 1, 1, 1, 1, 1,
-               relu=relu, dtype=x2.dtype, out_dtype=odt)
+        _plain_gemm(x2, wc, buf, bias_f, M, out_f, in_f, in_f, in_f, ldc, relu, x2.dtype, odt)
         y = buf[:, :out_f] if ldc != out_f else buf
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.bias_ref = bias
@@ -2117,8 +2143,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = linear_weight_t(weight, cdt, outp)   # [in, outp]
             dx = torch.empty((M, in_f), dtype=cdt, device=dy.device)
-            _igemm(dyp, wt, dx, None, None, taps, M, in_f, outp, 1, outp, outp, in_f, 1, 1, 1, 1, 1, 1,
-                   dtype=cdt, out_dtype=cdt)
+            _plain_gemm(dyp, wt, dx, None, M, in_f, outp, outp, outp, in_f, False, cdt, cdt)
             dx = dx.reshape(*lead, in_f)
         if ctx.needs_input_grad[1]:
             splits, pps = C().wgrad_choose_splits(M, outp, in_f, _dt(cdt))
