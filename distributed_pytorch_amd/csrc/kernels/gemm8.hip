@@ -80,7 +80,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const Gemm8Params p) {
 
   const uint32_t tiles_n = (p.N + 255) / 256;
   const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt0 = lid / tiles_n, nt0 = lid - mt0 * tiles_n;
+  // grouped order: 8 M tiles x every N tile run back to back on one XCD (xcd_remap hands each XCD a contiguous range of
+  // lid), so the 8 A panels stay in that XCD's L2 while the B panels stream past once per group
+  const uint32_t tiles_m = (p.M + 255) / 256;
+  const uint32_t per_group = 8 * tiles_n;
+  const uint32_t grp = lid / per_group, in_grp = lid - grp * per_group;
+  const uint32_t first_m = grp * 8;
+  const uint32_t gm = min(8u, tiles_m - first_m);
+  const int mt0 = (int)(first_m + in_grp % gm), nt0 = (int)(in_grp / gm);
   const int m0 = mt0 * 256, n0 = nt0 * 256;
   const int nk = p.K / 64;
   const int nhalf = 4 * nk;
