@@ -71,6 +71,7 @@ PYBIND11_MODULE(_C, m) {
   m.def("igemm_axf_ok", &igemm_axf_ok);
   m.attr("IGEMM_ROW3") = (int)kIgemmRow3;
   m.def("igemm_set_row3", &igemm_set_row3);
+  m.def("igemm_set_tail_min", &igemm_set_tail_min);
   m.def("igemm_set_lean", &igemm_set_lean);
   m.def("igemm_set_lean_ablate", &igemm_set_lean_ablate);
   m.def("igemm_set_nt_store", &igemm_set_nt_store);

@@ -120,7 +120,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       if (i < first || i >= last) continue;
       const uint32_t m = m0 + (tid + i * 256) / CE;
       const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0, no scatter
-      const size_t goff = ok ? ((size_t)m * p.ldc + ncol) * sizeof(TOut) : 0;
+      const size_t goff = ok ? ((size_t)m * p.ldc + gofs + ncol) * sizeof(TOut) : 0;   // grouped: this group's slice
       px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
       if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);
       pbits[i] = p.bn_relu == 3 ? reinterpret_cast<const uint8_t*>(p.bn_z)[goff / 16] : 0u;
@@ -192,11 +192,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   if constexpr (BNB) {
 #pragma unroll
     for (int j = 0; j < VECO; ++j) {
-      const int c = ncol + j < p.N ? ncol + j : 0;
+      // coef[4][stats_ld]: stats_ld = all channels of the BN (== N for a dense launch)
+      const long c = gofs + (ncol + j < p.N ? ncol + j : 0);
       bmu[j] = p.bn_coef[c];
-      bis[j] = p.bn_coef[p.N + c];
-      bsc[j] = p.bn_coef[2 * p.N + c];
-      bsh[j] = p.bn_coef[3 * p.N + c];
+      bis[j] = p.bn_coef[p.stats_ld + c];
+      bsc[j] = p.bn_coef[2 * (long)p.stats_ld + c];
+      bsh[j] = p.bn_coef[3 * (long)p.stats_ld + c];
     }
   }
 #pragma unroll
@@ -329,9 +330,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
 
 // BM: pixel rows per block, BN: output channels per block, BKB: bytes of K per row per K tile.
 // 256 threads = 2 (pixel) x 2 (channel) waves.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB, bool AXF = false>
+// TAIL (with ALIGNED): Cred is a multiple of 16 bytes but not of the K tile (grouped convolutions with 24 / 56 / 120
+// channels per group -- RegNet): every tap takes ceil(Cred / BK) K tiles and the chunks of the last one that lie
+// beyond the tap's channels are loaded from offset 0 and zeroed when the tile is written to LDS.
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB, bool AXF = false,
+          bool TAIL = false>
 __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   static_assert(!AXF || (ALIGNED && sizeof(T) == 2), "apply-on-load: aligned 16-bit problems");
+  static_assert(!TAIL || (ALIGNED && !AXF && !BNB), "K-tile tails: plain aligned launches");
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
   constexpr int CPR = BKB / 16;          // 16-byte chunks per tile row
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
     axf_fill_table<T>(axf_tab, p.a_scale, p.a_shift, p.Cred, tid, 256);
     __syncthreads();
   }
-  const int kpt = ALIGNED ? p.Cred / BK : 1;           // K tiles per tap
+  const int kpt = ALIGNED ? (TAIL ? (p.Cred + BK - 1) / BK : p.Cred / BK) : 1;           // K tiles per tap
   const int cpt = p.Cred / VEC;                        // chunks per tap
   const int nk = ALIGNED ? p.ntaps * kpt : (p.ntaps * cpt + CPR - 1) / CPR;
 
@@ -411,6 +417,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
   // 32-bit byte offsets; a K tile inside the tap is "scalar base + offset" loads with no vector address
   // arithmetic at all.  Counters showed the old per-tile 64-bit address math made the loop issue bound.
   uint32_t aoff[A_IT], amask[A_IT], boff[B_IT], bmask[B_IT];
+  uint32_t tmask = 0xffffffffu;                        // TAIL: this thread's chunk of the tile in ra/rb is inside the tap
   size_t kb_tap = 0;
   int lt_tap = 0, lt_kc = 0;                           // next K tile to load: tap, tile inside the tap
   if (ALIGNED) {
@@ -445,9 +452,20 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       // unconditional loads (out-of-image rows read offset 0 and are masked when the tile is written to
       // LDS, after the MFMAs of the current tile): no branch and no wait between the loads and the compute
-      for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + aoff[i]);
+      for (int i = 0; i < A_IT; ++i) {
+        if constexpr (TAIL) {
+          const bool cv = c0 + ch * VEC < p.Cred;
+          tmask = cv ? 0xffffffffu : 0u;
+          ra[i] = *reinterpret_cast<const uint4*>(Ak + (cv ? aoff[i] : 0u));
+        } else {
+          ra[i] = *reinterpret_cast<const uint4*>(Ak + aoff[i]);
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bk + boff[i]);
+      for (int i = 0; i < B_IT; ++i) {
+        if constexpr (TAIL) rb[i] = *reinterpret_cast<const uint4*>(Bk + (tmask ? boff[i] : 0u));
+        else rb[i] = *reinterpret_cast<const uint4*>(Bk + boff[i]);
+      }
       if (++lt_kc == kpt) {
         lt_kc = 0;
         ++lt_tap;
@@ -486,14 +504,16 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
       const int row = (tid + i * 256) / CPR;
       uint4 v = ra[i];
       if constexpr (AXF) v = axf_apply<T>(v, axf_tab + axf_q * (32 / (int)sizeof(T)));
-      v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
+      const uint32_t am = TAIL ? amask[i] & tmask : amask[i];
+      v.x &= am; v.y &= am; v.z &= am; v.w &= am;
       *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = (tid + i * 256) / CPR;
       uint4 v = rb[i];
-      v.x &= bmask[i]; v.y &= bmask[i]; v.z &= bmask[i]; v.w &= bmask[i];
+      const uint32_t bm = TAIL ? bmask[i] & tmask : bmask[i];
+      v.x &= bm; v.y &= bm; v.z &= bm; v.w &= bm;
       *reinterpret_cast<uint4*>(sb + row * LDR + ch * 16) = v;
     }
   };
@@ -987,7 +1007,8 @@ void launch_glds(const IgemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)p.groups), dim3(256), lds, stream, p);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB = false, bool AXF = false>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool ALIGNED, bool BNB = false, bool AXF = false,
+          bool TAIL = false>
 void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + BN) * LDR;
@@ -997,7 +1018,8 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   constexpr int max_lds = 2 * stage_bytes + axf_bytes > epi_bytes ? 2 * stage_bytes + axf_bytes : epi_bytes;
   // a single K tile (1x1 convolutions with few input channels) needs no second staging buffer
   constexpr int BK = BKB / (int)sizeof(T), VEC = 16 / (int)sizeof(T), CPR = BKB / 16;
-  const int nk = ALIGNED ? p.ntaps * (p.Cred / BK) : (p.ntaps * (p.Cred / VEC) + CPR - 1) / CPR;
+  const int nk = ALIGNED ? p.ntaps * (TAIL ? (p.Cred + BK - 1) / BK : p.Cred / BK)
+                         : (p.ntaps * (p.Cred / VEC) + CPR - 1) / CPR;
   int lds = (nk > 1 ? 2 : 1) * stage_bytes;
   if (AXF) {            // the (scale, shift) table sits behind BOTH staging buffers
     if (p.Cred > kAxfMaxCred) throw std::invalid_argument("igemm: apply-on-load supports at most 2048 reduction channels");
@@ -1005,7 +1027,7 @@ void launch_cfg(const IgemmParams& p, hipStream_t stream) {
   }
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED, BNB, AXF>;
+  auto kern = igemm_kernel<T, TOut, BM, BN, BKB, MINB, ALIGNED, BNB, AXF, TAIL>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1035,6 +1057,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int g_force_cfg = -1;
 int g_row3_mode = -1;
 int g_nt_store = 0;
+int g_tail_min = 16;      // K-tile tails (TAIL kernels) from this many reduction channels per tap; 0: never (8: measured a loss)
 
 // Pure function of the problem: the stats slab allocation (igemm_stats_rows) must agree with the launch.
 // Measured (MI355X, batch 256 ResNet-50 shapes): 64-byte K tiles (40 KB LDS, 3-4 blocks/CU) win whenever
@@ -1120,6 +1143,15 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
   if (!aligned) {
     if (p.flags & kIgemmBnBwd)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs a 16-bit, 64-byte aligned problem");
+    if constexpr (EXT) {
+      // 16-byte but not 64-byte aligned reduction (RegNet group widths): per-tap K tiles with a masked tail keep
+      // the per-tap 32-bit addressing of the aligned kernels instead of the per-chunk 64-bit gather below
+      if (fits32 && g_force_cfg < 0 && g_tail_min > 0 && p.Cred >= g_tail_min) {
+        if (p.N > 64) launch_cfg<T, TOut, 128, 128, 64, 2, true, false, false, true>(p, stream);
+        else launch_cfg<T, TOut, 128, 64, 64, 2, true, false, false, true>(p, stream);
+        return;
+      }
+    }
     if (p.N > 64) launch_cfg<T, TOut, 128, 128, 64, 2, false>(p, stream);
     else launch_cfg<T, TOut, 128, 64, 64, 2, false>(p, stream);
     return;
@@ -1174,7 +1206,8 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     const int veco_g = out_dtype == kF32 ? 4 : 8;
     if (p.a_gstride % vec || p.b_gstride % vec || p.c_gstride % veco_g || p.groups > 65535)
       throw std::invalid_argument("igemm: group slices must start on 16-byte boundaries");
-    if (p.flags & kIgemmBnBwd) throw std::invalid_argument("igemm: fused BN-backward reduction is dense only");
+    if ((p.flags & kIgemmBnBwd) && (p.c_gstride != p.N || p.stats_ld != p.ldc || (long)p.groups * p.N != p.ldc))
+      throw std::invalid_argument("igemm: grouped BN-backward reduction needs the groups to tile the channel rows");
   }
   if (p.stats_ld <= 0) p.stats_ld = p.N;
   {
@@ -1195,7 +1228,7 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     if (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr ||
         ((p.bn_relu == 1 || p.bn_relu == 3) && p.bn_z == nullptr))
       throw std::invalid_argument("igemm: fused BN-backward reduction needs stats slab, bn_x, bn_coef (and bn_z)");
-    if (p.N % veco != 0 || p.ldc != p.N)
+    if (p.N % veco != 0 || p.ldc != p.stats_ld)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs dense rows of whole 16-byte chunks");
   }
   if ((p.flags & kIgemmDense1) && g_force_cfg < 0 && gemm_lean_try(p, dtype, out_dtype, stream)) {
@@ -1228,6 +1261,7 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 
 void igemm_force_config(int cfg) { g_force_cfg = cfg; }
 void igemm_set_row3(int mode) { g_row3_mode = mode; }
+void igemm_set_tail_min(int cred) { g_tail_min = cred; }
 void igemm_set_nt_store(int mode) { g_nt_store = mode; }   // 0: by size (nt_min_bytes), 1: always, -1: never
 int igemm_num_configs() { return kNumCfgs; }
 

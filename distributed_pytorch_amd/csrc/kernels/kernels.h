@@ -64,6 +64,7 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 void igemm_force_config(int cfg);
 // tuning hook for the filter-row kernel: -1 automatic, 0 never, 1 64-byte K tiles, 2 128-byte K tiles
 void igemm_set_row3(int mode);
+void igemm_set_tail_min(int cred);   // K-tile tails for 16-byte aligned reductions of >= cred channels (0: off)
 // gemm_lean.hip: takes single-tap 16-bit launches (kIgemmDense1) it covers, false = run the general kernel.
 bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
 void igemm_set_lean(int mode);

@@ -35,6 +35,8 @@ def C():
         _C = backend.require()
         _C.bn_set_reverse(_BN_REVERSE)
         _C.igemm_set_row3(int(os.environ.get("DPA_IGEMM_ROW3", "-1")))   # filter-row kernel: -1 auto, 0 off
+        if "DPA_IGEMM_TAIL_MIN" in os.environ:          # masked K-tile tails (grouped RegNet widths): min channels, 0 off
+            _C.igemm_set_tail_min(int(os.environ["DPA_IGEMM_TAIL_MIN"]))
         _C.igemm_set_nt_store(int(os.environ.get("DPA_IGEMM_NT", "0")))  # 0: by size, 1: always, -1: never
         _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
         if "DPA_BN_GRID" in os.environ:          # workgroups of the BN streaming passes (default 1280, see bn.hip)
@@ -498,6 +500,10 @@ def join_side_stream() -> None:
 
 _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") == "1"
 # size window (MiB of the BN input) inside which the fusion is taken -- tuning hook
+# the same fusion in the GROUPED data gradient (ResNeXt / RegNet 3x3): implemented and tested, off by default -- a
+# group's reduction is only 9 * 64 channels deep, too short to hide the epilogue's extra operand loads: resnext50_32x4d
+# 8,765 -> 8,675 img/s, resnext101_32x8d 3,019 -> 2,994 img/s with it on (profiles/r2/group_bnb_ab.txt)
+_FUSE_BN_BWD_GROUPED = os.environ.get("DPA_FUSE_BN_BWD_GROUPED", "0") == "1"
 _FUSE_BN_BWD_MIN = int(float(os.environ.get("DPA_FUSE_BN_BWD_MIN_MB", "0")) * 2 ** 20)
 _FUSE_BN_BWD_MAX = int(float(os.environ.get("DPA_FUSE_BN_BWD_MAX_MB", "1e9")) * 2 ** 20)
 # data_ptr of a freshly produced data gradient -> (partial slab, data_ptr of the BN input it was reduced
@@ -736,6 +742,9 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
 # ------------------------------------------------------------------------------------------
 # grouped convolution (ResNeXt cardinality, depthwise): ONE launch per pass, grid.y = group
 # ------------------------------------------------------------------------------------------
+_GROUP_ALIGN = int(os.environ.get("DPA_GROUP_ALIGN", "0"))
+
+
 def group_merge(groups: int, Cg: int, Kg: int, vec: int) -> int:
     """How many consecutive groups one MFMA tile column block covers.
 
@@ -751,7 +760,16 @@ def group_merge(groups: int, Cg: int, Kg: int, vec: int) -> int:
         raise ValueError("grouped conv2d: %d groups of %d -> %d channels cannot be laid out in 16-byte vectors"
                          % (groups, Cg, Kg))
     fit = [m for m in ok if m * Kg <= 64]
-    return max(fit) if fit else min(ok)
+    best = max(fit) if fit else min(ok)
+    if _GROUP_ALIGN > 0 and vec == 8 and ((best * Cg) % 32 or (best * Kg) % 32):
+        # 64-byte K tiles (the LDS-DMA "aligned" kernels) need 32-channel slices in BOTH directions (forward reduces
+        # over m*Cg, the data gradient over m*Kg): RegNet group widths 24 / 56 / 112 miss that and fall to the
+        # gather kernels.  Trade block-diagonal zeros for the fast path, up to _GROUP_ALIGN merged channels.
+        # Measured a loss (regnet_y_8gf, 56-wide groups merged by 4: 4,074 -> 3,607 img/s), so off by default.
+        al = [m for m in ok if (m * Cg) % 32 == 0 and (m * Kg) % 32 == 0 and max(m * Cg, m * Kg) <= _GROUP_ALIGN]
+        if al:
+            best = min(al)
+    return best
 
 
 def _gw_src(w: torch.Tensor, Gs: int, m: int) -> torch.Tensor:
@@ -794,7 +812,8 @@ def group_weight_t(w: torch.Tensor, dtype: torch.dtype, groups: int, m: int) -> 
 
 class _GroupConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad):
+    def forward(ctx, x, weight, bias, stride, padding, groups, relu, want_stats, needs_input_grad, bnsrc=None):
+        x_in = x
         x = x if x.is_contiguous() else x.contiguous()
         NB, IH, IW, Cx = x.shape
         K, Cg, R, S = weight.shape
@@ -824,6 +843,16 @@ class _GroupConvFn(torch.autograd.Function):
                relu=relu, dtype=x.dtype, out_dtype=x.dtype, groups=(Gs, Cin, Kout * R * S * Cin, Kout, K))
         ctx.geom = (stride, padding, groups, m, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
+        # x is the output of a training-mode BatchNorm (ResNeXt / RegNet bottlenecks): the stride-1 data gradient
+        # reduces that BN's backward sums in its epilogue, one group slice per launch row (see _ConvFn.forward)
+        ctx.bnsrc = None
+        if bnsrc is not None:
+            bnsrc.uses += 1
+            if _FUSE_BN_BWD and _FUSE_BN_BWD_GROUPED and x is x_in and (sh, sw) == (1, 1) \
+                    and x.dtype != torch.float32 and Kout % 32 == 0 \
+                    and Cin % _vec(x.dtype) == 0 and bnsrc.x.shape == x.shape and bnsrc.x.dtype == x.dtype \
+                    and _FUSE_BN_BWD_MIN <= x.numel() * x.element_size() <= _FUSE_BN_BWD_MAX:
+                ctx.bnsrc = bnsrc
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.set_materialize_grads(False)
         if want_stats:
@@ -832,8 +861,9 @@ class _GroupConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dstats=None):
+        src, ctx.bnsrc = ctx.bnsrc, None
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, weight, y = ctx.saved_tensors
         (sh, sw), (ph, pw), groups, m, relu, needs_input_grad, has_bias = ctx.geom
         NB, IH, IW, Cx = x.shape
@@ -859,9 +889,16 @@ class _GroupConvFn(torch.autograd.Function):
                 if not taps or SH <= 0 or SW <= 0:
                     continue
                 scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
-                _igemm(dy, wt, dx, None, None, _tap_table(dy.device, taps), NB * SH * SW, Cin, Kout, len(taps), K,
+                slab = bnred = None
+                if src is not None and src.uses == 1 and scatter is None and len(classes) == 1:
+                    bnred = (src.x, x if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode)
+                    rows = C().igemm_stats_rows(NB * SH * SW, Cin, Kout, len(taps), _dt(dy), _dt(dy))
+                    slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
+                _igemm(dy, wt, dx, None, slab, _tap_table(dy.device, taps), NB * SH * SW, Cin, Kout, len(taps), K,
                        R * S * Kout, Cx, OH, OW, 1, 1, SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype,
-                       groups=(Gs, Kout, Cin * R * S * Kout, Cin, 0))
+                       groups=(Gs, Kout, Cin * R * S * Kout, Cin, Cx if slab is not None else 0), bnred=bnred)
+                if slab is not None:
+                    _pending_bnred[dx.data_ptr()] = (slab, src.x.data_ptr(), dx._version)
         if ctx.needs_input_grad[1]:
             Ktot = R * S * Cin
             splits, pps = C().wgrad_choose_splits(M, Kout, Ktot, _dt(dy), Gs)
@@ -885,7 +922,7 @@ class _GroupConvFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
             db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 _DW_DIRECT = os.environ.get("DPA_DW_DIRECT", "1") == "1"
@@ -983,7 +1020,7 @@ def group_conv2d(x, weight, bias, stride, padding, groups, relu, want_stats, nee
                                           bool(needs_input_grad))
         return (y, stats) if want_stats else y
     y, stats = _GroupConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), int(groups), bool(relu),
-                                  bool(want_stats), bool(needs_input_grad))
+                                  bool(want_stats), bool(needs_input_grad), getattr(x, "_dpa_bn", None))
     return (y, stats) if want_stats else y
 
 

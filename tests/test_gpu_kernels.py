@@ -534,6 +534,47 @@ def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     assert (got - want).abs().max().item() <= 1e-4 * scale, (got - want).abs().max().item() / scale
 
 
+@pytest.mark.parametrize("groups,ch", [(32, 128), (4, 128), (8, 512)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_grouped_dgrad_fuses_bn_backward(groups, ch, relu):
+    """BatchNorm (+ReLU) -> stride-1 grouped 3x3 convolution (ResNeXt / RegNet bottleneck): the grouped data gradient
+    reduces the BN's backward sums in its epilogue, one group slice per launch row.  Same gradients as with the
+    fusion switched off (the stand-alone column reduction), and the BN really took the fused slab."""
+    from distributed_pytorch_amd.ops import hip_ops
+    dt = torch.bfloat16
+    torch.manual_seed(9)
+    N, H = 4, 14
+    x0 = (torch.randn(N, H, H, ch, device=DEV) * 1.3 + 0.2).to(dt)
+    w0 = (torch.randn(ch, ch // groups, 3, 3, device=DEV) / (9 * ch / groups) ** 0.5)
+    w0 = w0.contiguous(memory_format=torch.channels_last)
+    g0, b0 = torch.rand(ch, device=DEV) + 0.5, torch.randn(ch, device=DEV) * 0.2
+    gy = torch.randn(N, H, H, ch, device=DEV).to(dt)
+
+    def run(fuse):
+        old = hip_ops._FUSE_BN_BWD, hip_ops._FUSE_BN_BWD_GROUPED
+        hip_ops._FUSE_BN_BWD = hip_ops._FUSE_BN_BWD_GROUPED = fuse      # (the grouped fusion is off by default)
+        try:
+            x = x0.clone().requires_grad_(True)
+            w, g, b = (t.clone().requires_grad_(True) for t in (w0, g0, b0))
+            z = F.batch_norm(x, g, b, None, None, None, True, 0.1, 1e-5, relu=relu)
+            y = F.conv2d(z, w, None, 1, 1, groups=groups)
+            before = dict(hip_ops.bn_bwd_counts)
+            y.backward(gy)
+            took = hip_ops.bn_bwd_counts["fused"] - before["fused"]
+            return x.grad, g.grad, b.grad, w.grad, took
+        finally:
+            hip_ops._FUSE_BN_BWD, hip_ops._FUSE_BN_BWD_GROUPED = old
+
+    dx_f, dg_f, db_f, dw_f, took_f = run(True)
+    dx_r, dg_r, db_r, dw_r, took_r = run(False)
+    assert took_f == 1 and took_r == 0
+    assert torch.equal(dw_f, dw_r)
+    for a, b, what in ((dg_f, dg_r, "dgamma"), (db_f, db_r, "dbeta")):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-4 * scale, what
+    _close(dx_f, dx_r, dt, scale=0.25, what="dx fused vs reduced")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cat_channels_ceil_maxpool_avgpool(dtype):
     torch.manual_seed(11)
@@ -581,6 +622,10 @@ GROUP_CASES = [
     (3, 30, 20, 16, 16, 16, 3, 1, 1),       # sliding-window kernel over several strips, last one ragged
     (2, 12, 16, 24, 24, 24, 5, 1, 1),       # 5x5 with padding 1 (output smaller than the input)
     (2, 16, 12, 32, 32, 32, 3, 2, 1),       # stride-2 backward-data on 2x2 blocks, non-square
+    (2, 14, 14, 224, 224, 4, 3, 1, 1),      # RegNetY-8GF: 56 per group -> two K tiles per tap, the second with a masked tail
+    (3, 15, 13, 112, 112, 2, 3, 2, 1),      # the same width, stride 2, odd extents, the LAST group's tail ends the tensor row
+    (2, 7, 7, 240, 240, 2, 3, 1, 1),        # RegNetX-8GF: 120 per group (four K tiles, 8 channels masked)
+    (2, 9, 9, 96, 144, 2, 3, 1, 1),         # 48 -> 72 per group: tails of different length forward and backward
 ]
 
 
