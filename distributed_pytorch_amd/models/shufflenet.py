@@ -46,6 +46,7 @@ class _Layout:
             off += _round_up(n, vec)
         self.pos, self.width, self.n = pos, off, sum(segs)
         self.identity = self.width == self.n
+        self.single = len(segs) == 1              # the padding is one tail: scatter == pad, gather == a leading slice
         self._idx: Dict[torch.device, torch.Tensor] = {}
 
     @classmethod
@@ -67,9 +68,31 @@ def _scatter(p: torch.Tensor, dim: int, lay: _Layout, fill: float = 0.0) -> torc
     """``p`` with its ``dim`` spread over the padded layout (differentiable; ``fill`` in the padding)."""
     if lay.identity:
         return p
+    if lay.single:          # one launch forward, a view backward (these models are host-launch bound)
+        return torch.nn.functional.pad(p, [0, 0] * (p.dim() - 1 - dim) + [0, lay.width - lay.n], value=fill)
     shape = list(p.shape)
     shape[dim] = lay.width
     return p.new_full(shape, fill).index_copy(dim, lay.index(p.device), p)
+
+
+def _padded_running_stats(bn: BatchNorm2d, lay: _Layout):
+    """Running statistics in the padded layout.  Single-segment layouts keep them PERSISTENTLY padded: the module's
+    ``running_mean`` / ``running_var`` buffers become leading views of the padded tensors the kernels update in place
+    (checkpoints still see torchvision's shapes), which removes eight small launches per BatchNorm and step.  Returns
+    (rm, rv, copy_back)."""
+    if bn.running_mean is None:
+        return None, None, False
+    if not lay.single:
+        with torch.no_grad():
+            return _scatter(bn.running_mean, 0, lay), _scatter(bn.running_var, 0, lay, 1.0), True
+    pad = getattr(bn, "_dpa_pad_stats", None)
+    if pad is None or pad[0].shape[0] != lay.width or pad[0].data_ptr() != bn.running_mean.data_ptr() \
+            or pad[1].data_ptr() != bn.running_var.data_ptr():
+        with torch.no_grad():           # first call, or the module was moved / reloaded since
+            rm, rv = _scatter(bn.running_mean, 0, lay), _scatter(bn.running_var, 0, lay, 1.0)
+        bn.running_mean, bn.running_var = rm[:lay.n], rv[:lay.n]
+        pad = bn._dpa_pad_stats = (rm, rv)
+    return pad[0], pad[1], False
 
 
 def _cba(x: torch.Tensor, conv: Conv2d, bn: BatchNorm2d, relu: bool, lin: _Layout, lout: _Layout,
@@ -89,12 +112,11 @@ def _cba(x: torch.Tensor, conv: Conv2d, bn: BatchNorm2d, relu: bool, lin: _Layou
     stats = None
     if fuse:
         y, stats = y
-    with torch.no_grad():
-        rm, rv = _scatter(bn.running_mean, 0, lout), _scatter(bn.running_var, 0, lout, 1.0)
+    rm, rv, copy_back = _padded_running_stats(bn, lout)
     out = F.batch_norm(y, _scatter(bn.weight, 0, lout, 1.0), _scatter(bn.bias, 0, lout), rm, rv,
                        bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, relu=relu, stats=stats,
                        group=bn.process_group)
-    if bn.training and not lout.identity:
+    if bn.training and copy_back:
         with torch.no_grad():
             idx = lout.index(rm.device)
             bn.running_mean.copy_(rm.index_select(0, idx))

@@ -82,3 +82,24 @@ def test_shufflenet_padded_channel_layout_equals_the_plain_one():
         assert q.grad is not None and torch.allclose(p.grad, q.grad, atol=1e-5, rtol=1e-4), n
     for (n, u), v in zip(a.named_buffers(), b.buffers()):
         assert torch.allclose(u.float(), v.float(), atol=1e-5), n
+    # the running statistics now live as leading views of persistently padded tensors: checkpoints keep torchvision's
+    # shapes, loading writes through the views, a second step and eval mode agree with the plain model
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(sb[k].shape == v.shape for k, v in sa.items())
+    la, lb = a(x), b(x)
+    assert torch.allclose(la, lb, atol=1e-5)
+    for (n, u), v in zip(a.named_buffers(), b.buffers()):
+        assert torch.allclose(u.float(), v.float(), atol=1e-5), n
+    c = models.create_model("shufflenet_v2_x1_0", num_classes=5)
+    b.load_state_dict(c.state_dict())
+    a.load_state_dict(c.state_dict())
+    a.eval(), b.eval()
+    with torch.no_grad():
+        assert torch.allclose(a(x), b(x), atol=1e-5)
+    import copy
+    d = copy.deepcopy(b)._apply(lambda t: t.clone())        # a "moved" module: the views are rebuilt on the next call
+    with torch.no_grad():
+        assert torch.allclose(d(x), a(x), atol=1e-5)
+    bn_d, bn_b = d.stage2[1].branch2[1], b.stage2[1].branch2[1]             # 58 channels stored as 64
+    assert bn_d.running_mean.data_ptr() == bn_d._dpa_pad_stats[0].data_ptr() != bn_b.running_mean.data_ptr()
+    assert bn_d.running_mean.shape == (58,) and bn_d._dpa_pad_stats[0].shape == (64,)
