@@ -567,9 +567,12 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 // Needs: taps in groups of 3 with equal dy and dx = x0, x0+1, x0+2 (same x0 for all groups), SX == 1, the output
 // grid as wide as the gathered image, Cred % BK == 0, operands addressable with 32 bits.
 // One LDS stage (the next stage waits in registers): 41 KB for 128x128x64B, three workgroups per CU.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB, bool AXF = false>
+// TAIL: Cred % BK != 0 (16-byte aligned group widths): ceil(Cred / BK) K tiles per filter row, the chunks beyond the
+// row's channels masked exactly as in igemm_kernel.
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB, bool AXF = false, bool TAIL = false>
 __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams p) {
   static_assert(!AXF || sizeof(T) == 2, "apply-on-load: 16-bit problems");
+  static_assert(!TAIL || (!AXF && !BNB), "K-tile tails: plain launches");
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BK = BKB / (int)sizeof(T);
   constexpr int CPR = BKB / 16;
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
   const char* __restrict__ Bg = reinterpret_cast<const char*>(p.B) + (size_t)blockIdx.y * p.b_gstride * sizeof(T);
 
   const int ngroups = p.ntaps / 3;
-  const int kpt = p.Cred / BK;
+  const int kpt = TAIL ? (p.Cred + BK - 1) / BK : p.Cred / BK;
 
   // ---- staged rows of this thread: flattened pixel q = m0 + row + x0, fixed for the whole kernel ------------
   const int ch = tid % CPR;
@@ -650,6 +653,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
 
   uint4 ra[A_IT], rb[3][B_IT];
   uint32_t aoff[A_IT], amask[A_IT];
+  uint32_t tmask = 0xffffffffu;          // TAIL: this thread's chunk of the staged K tile lies inside the channels
   size_t kb_tap[3] = {0, 0, 0};
   int lt_g = 0, lt_kc = 0;
   float* axf_tab = reinterpret_cast<float*>(smem + (AR + 3 * BN) * LDR);   // behind the stage
@@ -677,12 +681,14 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
     if constexpr (AXF) axf_q = lt_kc * CPR + ch;
     const char* Ak = Ag + (size_t)c0 * sizeof(T);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + aoff[i]);
+    if constexpr (TAIL) tmask = (c0 + ch * VEC < p.Cred) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + (TAIL && !tmask ? 0u : aoff[i]));
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const char* Bk = Bg + (kb_tap[t] + c0) * sizeof(T);
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) rb[t][i] = *reinterpret_cast<const uint4*>(Bk + boff[i]);
+      for (int i = 0; i < B_IT; ++i) rb[t][i] = *reinterpret_cast<const uint4*>(Bk + (TAIL && !tmask ? 0u : boff[i]));
     }
     if (++lt_kc == kpt) {
       lt_kc = 0;
@@ -696,7 +702,8 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
       if (row < AR) {
         uint4 v = ra[i];
         if constexpr (AXF) v = axf_apply<T>(v, axf_tab + axf_q * (32 / (int)sizeof(T)));
-        v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
+        const uint32_t am = TAIL ? amask[i] & tmask : amask[i];
+        v.x &= am; v.y &= am; v.z &= am; v.w &= am;
         *reinterpret_cast<uint4*>(sa + row * LDR + ch * 16) = v;
       }
     }
@@ -706,7 +713,8 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
       for (int i = 0; i < B_IT; ++i) {
         const int row = (tid + i * 256) / CPR;
         uint4 v = rb[t][i];
-        v.x &= bmask[i]; v.y &= bmask[i]; v.z &= bmask[i]; v.w &= bmask[i];
+        const uint32_t bm = TAIL ? bmask[i] & tmask : bmask[i];
+        v.x &= bm; v.y &= bm; v.z &= bm; v.w &= bm;
         *reinterpret_cast<uint4*>(sb + (t * BN + row) * LDR + ch * 16) = v;
       }
   };
@@ -756,7 +764,8 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
   igemm_epilogue<TOut, BM, BN, BNB>(p, acc, smem, m0, n0, mt);
 }
 
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB = false, bool AXF = false>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB = false, bool AXF = false,
+          bool TAIL = false>
 void launch_row3(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + 2 + 3 * BN) * LDR;
@@ -769,7 +778,7 @@ void launch_row3(const IgemmParams& p, hipStream_t stream) {
     if (p.Cred > kAxfMaxCred) throw std::invalid_argument("igemm: apply-on-load supports at most 2048 reduction channels");
     if (lds < stage_bytes + 8 * p.Cred) lds = stage_bytes + 8 * p.Cred;
   }
-  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB, AXF>;
+  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB, AXF, TAIL>;
   static bool attr_done = false;
   if (!attr_done && lds0 + 8 * kAxfMaxCred > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1057,6 +1066,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int g_force_cfg = -1;
 int g_row3_mode = -1;
 int g_nt_store = 0;
+int g_tail_row3 = 1;      // filter-row kernel with masked tails (set through igemm_set_tail_min: negative = off)
 int g_tail_min = 16;      // K-tile tails (TAIL kernels) from this many reduction channels per tap; 0: never (8: measured a loss)
 
 // Pure function of the problem: the stats slab allocation (igemm_stats_rows) must agree with the launch.
@@ -1147,6 +1157,12 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
       // 16-byte but not 64-byte aligned reduction (RegNet group widths): per-tap K tiles with a masked tail keep
       // the per-tap 32-bit addressing of the aligned kernels instead of the per-chunk 64-bit gather below
       if (fits32 && g_force_cfg < 0 && g_tail_min > 0 && p.Cred >= g_tail_min) {
+        if ((p.flags & kIgemmRow3) && g_row3_mode != 0 && g_tail_row3 && p.ntaps % 3 == 0 && p.SX == 1 &&
+            (int)p.div_ow.d == p.IW) {
+          if (p.N > 64) launch_row3<T, TOut, 128, 128, 64, 3, false, false, true>(p, stream);
+          else launch_row3<T, TOut, 128, 64, 64, 4, false, false, true>(p, stream);
+          return;
+        }
         if (p.N > 64) launch_cfg<T, TOut, 128, 128, 64, 2, true, false, false, true>(p, stream);
         else launch_cfg<T, TOut, 128, 64, 64, 2, true, false, false, true>(p, stream);
         return;
@@ -1261,7 +1277,10 @@ int igemm_stats_rows(int M, int N, int Cred, int ntaps, int dtype, int out_dtype
 
 void igemm_force_config(int cfg) { g_force_cfg = cfg; }
 void igemm_set_row3(int mode) { g_row3_mode = mode; }
-void igemm_set_tail_min(int cred) { g_tail_min = cred; }
+void igemm_set_tail_min(int cred) {       // negative: |cred| with the filter-row tail kernels off (A/B runs)
+  g_tail_row3 = cred >= 0;
+  g_tail_min = cred >= 0 ? cred : -cred;
+}
 void igemm_set_nt_store(int mode) { g_nt_store = mode; }   // 0: by size (nt_min_bytes), 1: always, -1: never
 int igemm_num_configs() { return kNumCfgs; }
 

@@ -840,7 +840,8 @@ class _GroupConvFn(torch.autograd.Function):
         if bias is not None:
             bias_f = bias.detach() if bias.dtype == torch.float32 else bias.detach().float()
         _igemm(x, wc, y, bias_f, stats, taps, M, Kout, Cin, R * S, Cx, R * S * Cin, K, IH, IW, sh, sw, OH, OW,
-               relu=relu, dtype=x.dtype, out_dtype=x.dtype, groups=(Gs, Cin, Kout * R * S * Cin, Kout, K))
+               relu=relu, dtype=x.dtype, out_dtype=x.dtype, groups=(Gs, Cin, Kout * R * S * Cin, Kout, K),
+               row3=(S == 3 and sw == 1 and pw == 1))
         ctx.geom = (stride, padding, groups, m, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
         # x is the output of a training-mode BatchNorm (ResNeXt / RegNet bottlenecks): the stride-1 data gradient
@@ -884,10 +885,13 @@ class _GroupConvFn(torch.autograd.Function):
             classes = _dgrad_classes(R, S, sh, sw, ph, pw)
             need_zero = any(len(t) == 0 for _, _, t in classes)
             dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
+            row3 = S == 3 and (sh, sw) == (1, 1) and pw == 1 and OW == IW       # filter-row kernel (see conv_dgrad)
             for py, px, taps in classes:
                 SH, SW = (IH - py + sh - 1) // sh, (IW - px + sw - 1) // sw
                 if not taps or SH <= 0 or SW <= 0:
                     continue
+                if row3:
+                    taps = tuple(sorted(taps))
                 scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
                 slab = bnred = None
                 if src is not None and src.uses == 1 and scatter is None and len(classes) == 1:
@@ -896,7 +900,8 @@ class _GroupConvFn(torch.autograd.Function):
                     slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
                 _igemm(dy, wt, dx, None, slab, _tap_table(dy.device, taps), NB * SH * SW, Cin, Kout, len(taps), K,
                        R * S * Kout, Cx, OH, OW, 1, 1, SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype,
-                       groups=(Gs, Kout, Cin * R * S * Kout, Cin, Cx if slab is not None else 0), bnred=bnred)
+                       groups=(Gs, Kout, Cin * R * S * Kout, Cin, Cx if slab is not None else 0), bnred=bnred,
+                       row3=row3)
                 if slab is not None:
                     _pending_bnred[dx.data_ptr()] = (slab, src.x.data_ptr(), dx._version)
         if ctx.needs_input_grad[1]:
