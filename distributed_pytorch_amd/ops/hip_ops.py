@@ -88,6 +88,7 @@ def bump_generation() -> None:
     global _generation
     _generation += 1
     _pending_bnred.clear()          # never carry a fused BN-backward slab across optimizer steps
+    _premasked.clear()
     _pending_mask.clear()
     _pending_compact.clear()
 
@@ -408,9 +409,11 @@ class _ConvFn(torch.autograd.Function):
         M = NB * OH * OW
         st = _stream()
         if relu:
-            dym = torch.empty_like(dy)
-            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
-            dy = dym
+            ent = _premasked.pop(dy.data_ptr(), None)
+            if ent is None or ent != (dy._version, _generation, y.data_ptr()):
+                dym = torch.empty_like(dy)
+                C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
+                dy = dym
         dx = dw = db = None
         wgrad_done = False
         _sk = grad_sink.sink_of(weight)
@@ -518,6 +521,12 @@ _pending_mask: Dict[int, tuple] = {}
 # data_ptr of the NaN placeholder a strided 1x1 branch returned as its input gradient -> (placeholder, compact gradient
 # [NB, OH, OW, C], (sy, sx), generation, full shape).  Consumed by the convolution that owns the alias the branch read.
 _pending_compact: Dict[int, tuple] = {}
+# data_ptr of a max-pool's input gradient that ALREADY carries the ReLU mask of the convolution that produced the pool's
+# input -> (version, generation, data_ptr of that convolution's output).  relu(x) followed by max-pool: a window's
+# arg-max is inactive exactly when the pooled value is 0, so the mask can be applied to the (4x or more smaller) pooled
+# gradient instead of the full-size one; the convolution's backward then skips its own relu_bwd pass (VGG, AlexNet).
+_premasked: Dict[int, tuple] = {}
+_POOL_PREMASK = os.environ.get("DPA_POOL_PREMASK", "1") == "1"
 _COMPACT_DRES = os.environ.get("DPA_COMPACT_DRES", "1") == "1"
 
 
@@ -735,6 +744,8 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
                                      and tuple(padding) == (0, 0) and x.dtype in (torch.bfloat16, torch.float16)
                                      and x.shape[-1] == Cw_ and Cw_ % 64 == 0 and K_ % 32 == 0 and x.is_contiguous()
                                      and needs_input_grad)
+    if relu:
+        y._dpa_relu_out = True      # a max-pool that consumes it may hand back an already masked gradient (_premasked)
     out = (y, stats) if want_stats else y
     return (out, alias) if skip else out
 
@@ -1465,7 +1476,8 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
 # ------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, s, p, ceil_mode=False):
+    def forward(ctx, x, k, s, p, ceil_mode=False, relu_in=False):
+        ctx.relu_src = x.data_ptr() if (relu_in and x.is_contiguous()) else 0
         x = x if x.is_contiguous() else x.contiguous()
         NB, IH, IW, Cc = x.shape
         OH, OW = _pool_out(IH, k[0], s[0], p[0], ceil_mode), _pool_out(IW, k[1], s[1], p[1], ceil_mode)
@@ -1475,24 +1487,36 @@ class _MaxPoolFn(torch.autograd.Function):
         idx = torch.empty((NB, OH, OW, Cc), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
         C().maxpool_fwd(x.data_ptr(), y.data_ptr(), _p(idx), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
                         p[0], p[1], _dt(x), _stream())
-        ctx.save_for_backward(idx)
+        if ctx.relu_src and idx is not None:
+            ctx.save_for_backward(idx, y)           # the pooled values: where they are 0 the whole window was inactive
+        else:
+            ctx.relu_src = 0
+            ctx.save_for_backward(idx)
         ctx.cfg = (k, s, p, OH, OW, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         k, s, p, OH, OW, xshape = ctx.cfg
         dy = dy if dy.is_contiguous() else dy.contiguous()
         NB, IH, IW, Cc = xshape
+        if ctx.relu_src:
+            y = ctx.saved_tensors[1]
+            dym = torch.empty_like(dy)
+            C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), _stream())
+            dy = dym
         dx = torch.empty(xshape, dtype=dy.dtype, device=dy.device)
         C().maxpool_bwd(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), NB, IH, IW, Cc, OH, OW, k[0], k[1], s[0], s[1],
                         p[0], p[1], _dt(dy), _stream())
-        return dx, None, None, None, None
+        if ctx.relu_src:
+            _premasked[dx.data_ptr()] = (dx._version, _generation, ctx.relu_src)
+        return dx, None, None, None, None, None
 
 
 def max_pool2d(x, k, s, p, ceil_mode=False):
-    return _MaxPoolFn.apply(x, tuple(k), tuple(s), tuple(p), bool(ceil_mode))
+    relu_in = _POOL_PREMASK and getattr(x, "_dpa_relu_out", False) and torch.is_grad_enabled() and x.requires_grad
+    return _MaxPoolFn.apply(x, tuple(k), tuple(s), tuple(p), bool(ceil_mode), bool(relu_in))
 
 
 def _pool_out(i, k, s, p, ceil_mode):

@@ -575,6 +575,51 @@ def test_grouped_dgrad_fuses_bn_backward(groups, ch, relu):
     _close(dx_f, dx_r, dt, scale=0.25, what="dx fused vs reduced")
 
 
+@pytest.mark.parametrize("k,s,p,ceil", [(2, 2, 0, False), (3, 2, 0, True), (3, 2, 1, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_relu_conv_maxpool_premasked_gradient(k, s, p, ceil, dtype):
+    """conv + ReLU -> max-pool (VGG / AlexNet): the pool applies the ReLU mask to the POOLED gradient (pooled value 0 <=>
+    the window's arg-max is inactive) and the convolution skips its full-size relu_bwd pass.  Bit-identical gradients,
+    and the pass really is skipped."""
+    from distributed_pytorch_amd.ops import hip_ops
+    torch.manual_seed(13)
+    x0 = torch.randn(3, 13, 14, 32, device=DEV).to(dtype)
+    w0 = (torch.randn(64, 32, 3, 3, device=DEV) / 17).contiguous(memory_format=torch.channels_last)
+    b0 = torch.randn(64, device=DEV) - 1.0           # many all-inactive windows
+    mod = hip_ops.C()
+    real = mod.relu_bwd
+    calls = []
+
+    def counting(*a):
+        calls.append(a[3])                            # element count of the masked tensor
+        return real(*a)
+
+    def run(on):
+        old = hip_ops._POOL_PREMASK
+        hip_ops._POOL_PREMASK = on
+        mod.relu_bwd = counting
+        del calls[:]
+        try:
+            x = x0.clone().requires_grad_(True)
+            w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = F.conv2d(x, w, b, 1, 1, relu=True)
+            z = F.max_pool2d(y, k, s, p, ceil_mode=ceil)
+            torch.manual_seed(14)
+            gz = torch.randn_like(z.float()).to(dtype)
+            z.backward(gz)
+            return x.grad, w.grad, b.grad, list(calls), y.numel(), z.numel(), (z == 0).float().mean().item()
+        finally:
+            hip_ops._POOL_PREMASK = old
+            mod.relu_bwd = real
+
+    dx1, dw1, db1, c1, ny, nz, dead = run(True)
+    dx0, dw0, db0, c0, _, _, _ = run(False)
+    assert 0.05 < dead < 0.95
+    assert c1 == [nz] and c0 == [ny]                  # masked the pooled gradient instead of the full-size one
+    assert torch.equal(dx1, dx0) and torch.equal(dw1, dw0) and torch.equal(db1, db0)
+    assert not hip_ops._premasked
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cat_channels_ceil_maxpool_avgpool(dtype):
     torch.manual_seed(11)
