@@ -68,6 +68,7 @@ PYBIND11_MODULE(_C, m) {
   m.attr("IGEMM_AXF") = (int)kIgemmAxf;
   m.attr("IGEMM_DENSE1") = (int)kIgemmDense1;
   m.attr("IGEMM_RSTRIDED") = (int)kIgemmRStrided;
+  m.attr("IGEMM_XMASK") = (int)kIgemmXMask;
   m.def("igemm_axf_ok", &igemm_axf_ok);
   m.attr("IGEMM_ROW3") = (int)kIgemmRow3;
   m.def("igemm_set_row3", &igemm_set_row3);

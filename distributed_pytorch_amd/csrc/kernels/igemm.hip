@@ -87,7 +87,9 @@ __device__ __forceinline__ uint4 axf_apply(const uint4& raw, const float* tab_q)
 // stores (+ bias, ReLU, fused accumulate, BatchNorm partial statistics).  All waves must be past their
 // last read of the staging buffers (barrier) and have no LDS-DMA in flight when they enter.
 // BNB (data-gradient launches with kIgemmBnBwd): the BatchNorm-backward partial sums are produced here.
-template <typename TOut, int BM, int BN, bool BNB>
+// XM (kIgemmXMask, filter-row data-gradient launches): the output is the gradient of a ReLU output x (= p.bn_x, same
+// layout as C): elements with x <= 0 are stored as 0, so the producer of x needs no relu_bwd pass of its own.
+template <typename TOut, int BM, int BN, bool BNB, bool XM = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&acc)[BN / 64][BM / 64],
                                                unsigned char* smem, int m0, int n0, int mt) {
   const long gofs = (long)blockIdx.y * p.c_gstride;      // first output channel of this group
@@ -127,7 +129,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     }
   };
   constexpr int E_HALF = E_IT > 1 ? E_IT / 2 : 1;
-  if constexpr (BNB) bnb_request(0, E_HALF);
+  if constexpr (BNB || XM) bnb_request(0, E_HALF);
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
 #pragma unroll
@@ -165,7 +167,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if constexpr (BNB) bnb_request(E_HALF, E_IT);
+  if constexpr (BNB || XM) bnb_request(E_HALF, E_IT);
 
   float s1[VECO], s2[VECO];
 #pragma unroll
@@ -235,6 +237,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
           }
         }
       }
+    }
+    if constexpr (XM) {        // whole chunks only (the launch checks N % VECO == 0)
+      Vec16<TOut> xb;
+      xb.raw = px[i];
+#pragma unroll
+      for (int j = 0; j < VECO; ++j)
+        if (!(xb.get(j) > 0.f)) v.set(j, 0.f);
     }
     if (ncol + VECO <= p.N) {
       if (p.flags & kIgemmNtStore) v.store_nt(dst);
@@ -569,8 +578,10 @@ __global__ __launch_bounds__(256, MINB) void igemm_kernel(const IgemmParams p) {
 // One LDS stage (the next stage waits in registers): 41 KB for 128x128x64B, three workgroups per CU.
 // TAIL: Cred % BK != 0 (16-byte aligned group widths): ceil(Cred / BK) K tiles per filter row, the chunks beyond the
 // row's channels masked exactly as in igemm_kernel.
-template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB, bool AXF = false, bool TAIL = false>
+template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB, bool AXF = false, bool TAIL = false,
+          bool XM = false>
 __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams p) {
+  static_assert(!XM || (!BNB && !AXF && !TAIL), "masked store: plain launches");
   static_assert(!AXF || sizeof(T) == 2, "apply-on-load: 16-bit problems");
   static_assert(!TAIL || (!AXF && !BNB), "K-tile tails: plain launches");
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -680,7 +691,6 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
     const int c0 = lt_kc * BK;
     if constexpr (AXF) axf_q = lt_kc * CPR + ch;
     const char* Ak = Ag + (size_t)c0 * sizeof(T);
-#pragma unroll
     if constexpr (TAIL) tmask = (c0 + ch * VEC < p.Cred) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const uint4*>(Ak + (TAIL && !tmask ? 0u : aoff[i]));
@@ -761,11 +771,11 @@ __global__ __launch_bounds__(256, MINB) void igemm_row3_kernel(const IgemmParams
     }
   }
 
-  igemm_epilogue<TOut, BM, BN, BNB>(p, acc, smem, m0, n0, mt);
+  igemm_epilogue<TOut, BM, BN, BNB, XM>(p, acc, smem, m0, n0, mt);
 }
 
 template <typename T, typename TOut, int BM, int BN, int BKB, int MINB, bool BNB = false, bool AXF = false,
-          bool TAIL = false>
+          bool TAIL = false, bool XM = false>
 void launch_row3(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (BM + 2 + 3 * BN) * LDR;
@@ -778,7 +788,7 @@ void launch_row3(const IgemmParams& p, hipStream_t stream) {
     if (p.Cred > kAxfMaxCred) throw std::invalid_argument("igemm: apply-on-load supports at most 2048 reduction channels");
     if (lds < stage_bytes + 8 * p.Cred) lds = stage_bytes + 8 * p.Cred;
   }
-  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB, AXF, TAIL>;
+  auto kern = igemm_row3_kernel<T, TOut, BM, BN, BKB, MINB, BNB, AXF, TAIL, XM>;
   static bool attr_done = false;
   if (!attr_done && lds0 + 8 * kAxfMaxCred > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1065,6 +1075,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int g_force_cfg = -1;
 int g_row3_mode = -1;
+thread_local bool t_xmask_done = false;      // the launched kernel applied kIgemmXMask itself
 int g_nt_store = 0;
 int g_tail_row3 = 1;      // filter-row kernel with masked tails (set through igemm_set_tail_min: negative = off)
 int g_tail_min = 16;      // K-tile tails (TAIL kernels) from this many reduction channels per tap; 0: never (8: measured a loss)
@@ -1140,6 +1151,17 @@ void dispatch_tiles(const IgemmParams& p, hipStream_t stream) {
       }
       // measured (scratch/row3_check.py, batch 1024): 64-byte K tiles win up to 256 channels, 128-byte from 512
       const bool k128 = p.Cred % (128 / ES) == 0 && (g_row3_mode == 2 || (g_row3_mode < 0 && p.Cred * ES >= 1024));
+      if (p.flags & kIgemmXMask) {           // data gradient stored through the ReLU mask of the tensor it belongs to
+        if (p.N > 64) {
+          if (k128) launch_row3<T, TOut, 128, 128, 128, 2, false, false, false, true>(p, stream);
+          else launch_row3<T, TOut, 128, 128, 64, 3, false, false, false, true>(p, stream);
+        } else {
+          if (k128) launch_row3<T, TOut, 128, 64, 128, 3, false, false, false, true>(p, stream);
+          else launch_row3<T, TOut, 128, 64, 64, 4, false, false, false, true>(p, stream);
+        }
+        t_xmask_done = true;
+        return;
+      }
       if (p.N > 64) {
         if (k128) launch_row3<T, TOut, 128, 128, 128, 2>(p, stream);
         else launch_row3<T, TOut, 128, 128, 64, 3>(p, stream);
@@ -1247,7 +1269,15 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     if (p.N % veco != 0 || p.ldc != p.stats_ld)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs dense rows of whole 16-byte chunks");
   }
-  if ((p.flags & kIgemmDense1) && g_force_cfg < 0 && gemm_lean_try(p, dtype, out_dtype, stream)) {
+  if (p.flags & kIgemmXMask) {
+    if (p.bn_x == nullptr || (p.flags & (kIgemmBnBwd | kIgemmScatter | kIgemmAxf)) || p.groups != 1 || p.ldc != p.N ||
+        p.N % veco != 0 || dtype != out_dtype)
+      throw std::invalid_argument("igemm: masked store needs a dense, unscattered launch with the mask source in bn_x");
+    p.bn_relu = 0;
+    p.bn_z = nullptr;
+  }
+  t_xmask_done = false;
+  if (!(p.flags & kIgemmXMask) && (p.flags & kIgemmDense1) && g_force_cfg < 0 && gemm_lean_try(p, dtype, out_dtype, stream)) {
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
@@ -1260,6 +1290,8 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
   else if (dtype == kF16 && out_dtype == kF32) dispatch_tiles<f16_t, float>(p, stream);
   else throw std::invalid_argument("igemm: unsupported dtype combination");
   DPA_CHECK_HIP(hipGetLastError());
+  if ((p.flags & kIgemmXMask) && !t_xmask_done)      // no masking kernel for this shape: one in-place elementwise pass
+    relu_bwd_launch(p.bn_x, p.C, p.C, (long)p.M * p.N, out_dtype, stream);
 }
 
 bool igemm_axf_ok(long ohow, int IH, int IW, int lda, int N, int Cred, int ldb, int dtype, int out_dtype, int groups) {

@@ -18,7 +18,7 @@ namespace dpa {
 // so every output pixel (oy, ox) reads input pixel (oy * SY, ox * SX): such launches may run the lean GEMM
 // (gemm_lean.hip: no tap bookkeeping, no padding masks).
 enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16,
-                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128 };
+                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128, kIgemmXMask = 256 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]

@@ -251,8 +251,9 @@ def _conv_out(i, k, s, p):
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
            scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False,
-           accum_mask=None, axf=None, rstride=None):
-    """``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
+           accum_mask=None, axf=None, rstride=None, xmask=None):
+    """``xmask``: a ReLU output with the layout of the result; result elements where it is <= 0 are stored as 0.
+    ``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
     ``rstride``: (OHc, OWc, sy, sx) -- ``accum`` is the COMPACT gradient [NB, OHc, OWc, N] of a stride-s 1x1 branch
     (added at the output pixels whose coordinates are multiples of s; lean GEMM only).
     ``row3``: the tap table is sorted into filter rows (dy, dx ascending, three taps per row): stride-1 "same"
@@ -269,6 +270,9 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
     if bnred is not None:               # (bn input, bn output or None, coef[4][N], relu mode)
         flags |= C().IGEMM_BN_BWD
         bn_x, bn_z, bn_coef, bn_relu = bnred[0].data_ptr(), _p(bnred[1]), bnred[2].data_ptr(), bnred[3]
+    if xmask is not None:
+        flags |= C().IGEMM_XMASK
+        bn_x = xmask.data_ptr()
     OHF = OWF = OSY = OSX = OY0 = OX0 = 0
     if scatter is not None:
         flags |= C().IGEMM_SCATTER
@@ -324,7 +328,7 @@ def _deliver(param, g):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip, bnsrc=None,
-                axf=None):
+                axf=None, relu_in=False):
         # axf: x is the RAW input of a training-mode BatchNorm + ReLU (a "deferred" BN output) and `axf` that BN's
         # coefficient table: forward and the weight gradient apply relu(scale * x + shift) while they stage the
         # operand, the normalised activation is never written (profiles/r2_notes.md)
@@ -360,6 +364,10 @@ class _ConvFn(torch.autograd.Function):
                            and sh in (2, 4) and x is x_in and Cx == Cw and K % 32 == 0 and not relu)
         ctx.geom = (stride, padding, relu, needs_input_grad, bias is not None)
         ctx.bias_ref = bias
+        # x is the output of a convolution + ReLU (VGG): the 3x3 stride-1 data gradient is stored through that ReLU's
+        # mask and the producer skips its relu_bwd pass (_premasked)
+        ctx.xmask = bool(relu_in and _DGRAD_XMASK and x is x_in and axf is None and x.dtype != torch.float32
+                         and (sh, sw) == (1, 1) and S == 3 and pw == 1 and Cx == Cw and K % 32 == 0)
         # x is the output of a training-mode BatchNorm: the data-gradient epilogue can produce that BN's
         # backward partial sums (stride 1: one launch covers every input pixel exactly once)
         ctx.bnsrc = None
@@ -398,7 +406,7 @@ class _ConvFn(torch.autograd.Function):
                 dalias = _expand_compact(compact)
             if amask is not None:
                 dalias = apply_bit_mask(dalias, amask)
-            return dalias, None, None, None, None, None, None, None, None, None, None
+            return dalias, None, None, None, None, None, None, None, None, None, None, None
         x, weight, y = ctx.saved_tensors
         axf = ctx.axf
         (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
@@ -461,7 +469,7 @@ class _ConvFn(torch.autograd.Function):
                                     accum_stride=compact[2])
             else:
                 dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (sh, sw), (ph, pw), accum=dalias, bnred=bnred,
-                                accum_mask=amask)
+                                accum_mask=amask, xmask=x if (ctx.xmask and bnred is None) else None)
         elif dalias is not None:
             if compact is not None:
                 dalias = _expand_compact(compact)
@@ -471,7 +479,7 @@ class _ConvFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
             db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 # Fused BN-backward reduction in the data-gradient epilogue (DPA_FUSE_BN_BWD=0 disables).  First measured a wash
@@ -527,6 +535,7 @@ _pending_compact: Dict[int, tuple] = {}
 # gradient instead of the full-size one; the convolution's backward then skips its own relu_bwd pass (VGG, AlexNet).
 _premasked: Dict[int, tuple] = {}
 _POOL_PREMASK = os.environ.get("DPA_POOL_PREMASK", "1") == "1"
+_DGRAD_XMASK = os.environ.get("DPA_DGRAD_XMASK", "0") == "1"     # the same for conv + ReLU -> 3x3 conv (dgrad epilogue)
 _COMPACT_DRES = os.environ.get("DPA_COMPACT_DRES", "1") == "1"
 
 
@@ -581,7 +590,8 @@ def apply_bit_mask(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return (t.contiguous().view(-1, vec) * bits.to(t.dtype)).view(t.shape)
 
 
-def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accum_mask=None, accum_stride=None):
+def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accum_mask=None, accum_stride=None,
+               xmask=None):
     NB, IH, IW, Cx = xshape
     K, Cw, R, S = weight.shape
     sh, sw = stride
@@ -622,11 +632,17 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
         if bnred is not None and scatter is None and len(classes) == 1 and K % 32 == 0:
             rows = C().igemm_stats_rows(NB * SH * SW, Cx, K, len(taps), _dt(dy), _dt(dy))
             slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
+        # dx is the gradient of a ReLU output (xmask): store it through that ReLU's mask (filter-row launches)
+        xm = xmask if (xmask is not None and slab is None and row3 and scatter is None and len(classes) == 1
+                       and not need_zero and rstride is None and Cx % _vec(dy.dtype) == 0
+                       and tuple(xmask.shape) == (NB, IH, IW, Cx) and xmask.is_contiguous()) else None
         _igemm(dy, wt, dx, None, slab, tt, NB * SH * SW, Cx, K, len(taps), K, R * S * K, Cx, OH, OW, 1, 1,
                SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
-               bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask, rstride=rstride)
+               bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask, rstride=rstride, xmask=xm)
         if slab is not None:
             _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version)
+        if xm is not None:
+            _premasked[dx.data_ptr()] = (dx._version, _generation, xm.data_ptr())
     return dx
 
 
@@ -733,7 +749,8 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
         if not ok:
             x, axf = materialize(x), None
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
-                                    bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None), axf)
+                                    bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None), axf,
+                                    bool(getattr(x, "_dpa_relu_out", False)))
     if alias is not None:
         # its gradient returns to _ConvFn.backward (and nowhere else): a BatchNorm that takes it as the residual may
         # hand back the UNMASKED gradient plus its ReLU bit mask instead of writing a masked copy
