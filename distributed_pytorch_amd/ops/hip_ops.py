@@ -535,7 +535,7 @@ _pending_compact: Dict[int, tuple] = {}
 # gradient instead of the full-size one; the convolution's backward then skips its own relu_bwd pass (VGG, AlexNet).
 _premasked: Dict[int, tuple] = {}
 _POOL_PREMASK = os.environ.get("DPA_POOL_PREMASK", "1") == "1"
-_DGRAD_XMASK = os.environ.get("DPA_DGRAD_XMASK", "0") == "1"     # the same for conv + ReLU -> 3x3 conv (dgrad epilogue)
+_DGRAD_XMASK = os.environ.get("DPA_DGRAD_XMASK", "1") == "1"     # the same for conv + ReLU -> 3x3 conv (dgrad epilogue)
 _COMPACT_DRES = os.environ.get("DPA_COMPACT_DRES", "1") == "1"
 
 

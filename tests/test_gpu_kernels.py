@@ -620,6 +620,55 @@ def test_relu_conv_maxpool_premasked_gradient(k, s, p, ceil, dtype):
     assert not hip_ops._premasked
 
 
+@pytest.mark.parametrize("row3", [-1, 0])
+@pytest.mark.parametrize("cin,cmid,cout", [(32, 64, 128), (64, 128, 64), (64, 512, 64)])
+def test_relu_conv_conv_masked_data_gradient(cin, cmid, cout, row3):
+    """conv + ReLU -> 3x3 conv (VGG): the second convolution's data gradient is stored through the first one's ReLU
+    mask (filter-row kernel epilogue; with the filter-row kernels switched off, the launcher's in-place fallback) and
+    the first convolution skips its relu_bwd pass.  Bit-identical gradients."""
+    from distributed_pytorch_amd.ops import hip_ops
+    dt = torch.bfloat16
+    torch.manual_seed(21)
+    x0 = torch.randn(3, 12, 10, cin, device=DEV).to(dt)
+    w1 = (torch.randn(cmid, cin, 3, 3, device=DEV) / (9 * cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b1 = torch.randn(cmid, device=DEV) * 0.5
+    w2 = (torch.randn(cout, cmid, 3, 3, device=DEV) / (9 * cmid) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b2 = torch.randn(cout, device=DEV) * 0.5
+    mod = hip_ops.C()
+    real = mod.relu_bwd
+    calls = []
+
+    def counting(*a):
+        calls.append(a[3])
+        return real(*a)
+
+    def run(on):
+        old = hip_ops._DGRAD_XMASK
+        hip_ops._DGRAD_XMASK = on
+        mod.relu_bwd = counting
+        mod.igemm_set_row3(row3)
+        del calls[:]
+        try:
+            x = x0.clone().requires_grad_(True)
+            ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+            y = F.conv2d(x, ps[0], ps[1], 1, 1, relu=True)
+            z = F.conv2d(y, ps[2], ps[3], 1, 1, relu=True)
+            torch.manual_seed(22)
+            z.backward(torch.randn_like(z.float()).to(dt))
+            return [x.grad] + [q.grad for q in ps], list(calls), y.numel(), z.numel()
+        finally:
+            hip_ops._DGRAD_XMASK = old
+            mod.relu_bwd = real
+            mod.igemm_set_row3(-1)
+
+    g1, c1, ny, nz = run(True)
+    g0, c0, _, _ = run(False)
+    assert c0 == [nz, ny] and c1 == [nz]              # the first convolution's pass is gone
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    assert not hip_ops._premasked
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cat_channels_ceil_maxpool_avgpool(dtype):
     torch.manual_seed(11)
