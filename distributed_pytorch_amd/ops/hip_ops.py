@@ -35,7 +35,7 @@ def C():
         _C = backend.require()
         _C.bn_set_reverse(_BN_REVERSE)
         _C.igemm_set_row3(int(os.environ.get("DPA_IGEMM_ROW3", "-1")))   # filter-row kernel: -1 auto, 0 off
-        if "DPA_IGEMM_TAIL_MIN" in os.environ:          # masked K-tile tails (grouped RegNet widths): min channels, 0 off
+        if "DPA_IGEMM_TAIL_MIN" in os.environ:          # masked K-tile tails: min channels per tap; 0 off; -n: n, no filter-row tails
             _C.igemm_set_tail_min(int(os.environ["DPA_IGEMM_TAIL_MIN"]))
         _C.igemm_set_nt_store(int(os.environ.get("DPA_IGEMM_NT", "0")))  # 0: by size, 1: always, -1: never
         _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
@@ -533,6 +533,9 @@ _pending_compact: Dict[int, tuple] = {}
 # input -> (version, generation, data_ptr of that convolution's output).  relu(x) followed by max-pool: a window's
 # arg-max is inactive exactly when the pooled value is 0, so the mask can be applied to the (4x or more smaller) pooled
 # gradient instead of the full-size one; the convolution's backward then skips its own relu_bwd pass (VGG, AlexNet).
+# (What autograd carries between the two nodes is then the gradient of the PRE-activation, not of the ReLU output: only a
+# hook / retain_grad() on that intermediate tensor can tell; any other consumer of it makes autograd hand the producer a
+# SUM, a new tensor, which matches no entry and takes the ordinary relu_bwd pass -- masking twice is idempotent.)
 _premasked: Dict[int, tuple] = {}
 _POOL_PREMASK = os.environ.get("DPA_POOL_PREMASK", "1") == "1"
 _DGRAD_XMASK = os.environ.get("DPA_DGRAD_XMASK", "1") == "1"     # the same for conv + ReLU -> 3x3 conv (dgrad epilogue)
