@@ -642,7 +642,11 @@ void maxpool_bwd_launch(const uint8_t* idx, const void* dy, void* dx, int NB, in
   PoolGeom g{NB, IH, IW, C, OH, OW, kh, kw, sh, sw, ph, pw};
   const long total = (long)NB * IH * IW * (C / (dtype == kF32 ? 4 : 8));
   if (total <= 0) return;
-  if (two_windows(kh, kw, sh, sw)) {
+  if (kh <= sh && kw <= sw) {
+    // non-overlapping windows (VGG's 2x2 stride 2): one candidate window per pixel instead of four
+    DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 1>), dim3(grid_for(total)), dim3(256), 0, s,
+                                                 idx, (const T*)dy, (T*)dx, g, total));
+  } else if (two_windows(kh, kw, sh, sw)) {
     DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T, 2>), dim3(grid_for(total)), dim3(256), 0, s,
                                                  idx, (const T*)dy, (T*)dx, g, total));
   } else if (kh <= 3 * sh && kw <= 3 * sw) {

@@ -198,7 +198,7 @@ def test_batch_norm_eval():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("k,s,p,H", [(3, 2, 1, 16), (3, 2, 0, 13), (2, 2, 0, 8), (3, 1, 1, 14), (5, 2, 2, 15), (5, 1, 2, 9)])
+@pytest.mark.parametrize("k,s,p,H", [(3, 2, 1, 16), (3, 2, 0, 13), (2, 2, 0, 8), (2, 2, 0, 9), (2, 3, 0, 11), (3, 1, 1, 14), (5, 2, 2, 15), (5, 1, 2, 9)])
 def test_max_pool(dtype, k, s, p, H):
     torch.manual_seed(4)
     x = torch.randn(3, H, H, 64, device=DEV).to(dtype).requires_grad_(True)
