@@ -88,6 +88,12 @@ def _padded_running_stats(bn: BatchNorm2d, lay: _Layout):
     pad = getattr(bn, "_dpa_pad_stats", None)
     if pad is None or pad[0].shape[0] != lay.width or pad[0].data_ptr() != bn.running_mean.data_ptr() \
             or pad[1].data_ptr() != bn.running_var.data_ptr():
+        bn._dpa_pad_stats = None
+        if bn.running_mean._base is not None or bn.running_var._base is not None:
+            # the buffers are views of somebody else's storage -- DistributedDataParallel re-homes every buffer into
+            # one flat arena that it broadcasts per step: leave them there and copy back after the kernel
+            with torch.no_grad():
+                return _scatter(bn.running_mean, 0, lay), _scatter(bn.running_var, 0, lay, 1.0), True
         with torch.no_grad():           # first call, or the module was moved / reloaded since
             rm, rv = _scatter(bn.running_mean, 0, lay), _scatter(bn.running_var, 0, lay, 1.0)
         bn.running_mean, bn.running_var = rm[:lay.n], rv[:lay.n]
@@ -118,9 +124,13 @@ def _cba(x: torch.Tensor, conv: Conv2d, bn: BatchNorm2d, relu: bool, lin: _Layou
                        group=bn.process_group)
     if bn.training and copy_back:
         with torch.no_grad():
-            idx = lout.index(rm.device)
-            bn.running_mean.copy_(rm.index_select(0, idx))
-            bn.running_var.copy_(rv.index_select(0, idx))
+            if lout.single:
+                bn.running_mean.copy_(rm[:lout.n])
+                bn.running_var.copy_(rv[:lout.n])
+            else:
+                idx = lout.index(rm.device)
+                bn.running_mean.copy_(rm.index_select(0, idx))
+                bn.running_var.copy_(rv.index_select(0, idx))
     return out
 
 

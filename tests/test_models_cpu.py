@@ -103,3 +103,26 @@ def test_shufflenet_padded_channel_layout_equals_the_plain_one():
     bn_d, bn_b = d.stage2[1].branch2[1], b.stage2[1].branch2[1]             # 58 channels stored as 64
     assert bn_d.running_mean.data_ptr() == bn_d._dpa_pad_stats[0].data_ptr() != bn_b.running_mean.data_ptr()
     assert bn_d.running_mean.shape == (58,) and bn_d._dpa_pad_stats[0].shape == (64,)
+    # buffers re-homed into a flat arena (what DistributedDataParallel does before it broadcasts them every step) stay
+    # there: the padded path copies back into the views instead of re-pointing the module's buffers
+    e = models.create_model("shufflenet_v2_x1_0", num_classes=5).train()
+    e.load_state_dict(c.state_dict())
+    e.force_vec = 8
+    items = [(m, n, t) for m in e.modules() for n, t in m._buffers.items() if t is not None and t.dtype == torch.float32]
+    flat = torch.empty(sum(t.numel() for _, _, t in items))
+    off = 0
+    for m, n, t in items:
+        v = flat[off:off + t.numel()].view(t.shape)
+        v.copy_(t)
+        m._buffers[n] = v
+        off += t.numel()
+    before = flat.clone()
+    a.train()
+    la, le = a(x), e(x)
+    assert torch.allclose(la, le, atol=1e-5)
+    assert not torch.equal(before, flat)                      # the arena itself received the new running statistics
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    for (n, u), v in zip(a.named_buffers(), e.buffers()):
+        assert torch.allclose(u.float(), v.float(), atol=1e-5), n
+        if v.dtype == torch.float32:
+            assert lo <= v.data_ptr() < hi, n
