@@ -48,6 +48,14 @@ def parse_args(argv=None):
                     help="1-GPU rehearsal of the multi-GPU path: process group of one rank + DDP wrapper + RCCL reducer")
     ap.add_argument("--dist-backend", default=os.environ.get("DPA_BENCH_BACKEND", "native"),
                     help="native (TcpStore + C++ RCCL communicator, default) | nccl (torch.distributed) | gloo")
+    ap.add_argument("--comm", default=os.environ.get("DPA_COMM", "rccl"), choices=["rccl", "peer", "auto", "torch"],
+                    help="rccl (default): C++ reducer calling RCCL; peer: two-shot all-reduce over hipIpc windows "
+                         "(csrc/comm/peer.hip), the only engine that lets ranks share a device")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks on the visible device(s), wrapping around: rehearses the N-rank GPU path on one "
+                         "MI355X (implies --comm peer; per-GPU numbers are NOT comparable to real N-GPU runs)")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16", "fp16"],
+                    help="dtype the fp32 gradient buckets travel in (auto = AMP dtype under O2, like Apex)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu = rehearsal of the launch / rendezvous / reducer logic without a GPU (tests)")
     args = ap.parse_args(argv)
@@ -55,6 +63,8 @@ def parse_args(argv=None):
         args.batch_size = 1024 if args.device == "cuda" else 8
     if args.dtype is None:
         args.dtype = "bf16" if args.device == "cuda" else "fp32"
+    if args.share_gpu:
+        args.comm = "peer"
     return args
 
 
@@ -68,6 +78,8 @@ def self_launch(args) -> int:
     from distributed_pytorch_amd import launch
 
     have = launch.device_count() if args.device == "cuda" else int(os.environ.get("DPA_NPROC_PER_NODE", args.gpus))
+    if args.share_gpu and have >= 1:
+        have = args.gpus
     if have < args.gpus:
         print("bench.py: --gpus %d requested but this node has %d GPU(s)" % (args.gpus, have), file=sys.stderr)
         return 2
@@ -106,6 +118,9 @@ def _emit(line: str) -> None:
 
 def run(args) -> None:
     _claim_stdout()
+    import faulthandler
+
+    faulthandler.enable()          # a native crash in one rank leaves its Python stack on stderr
     import torch
 
     from distributed_pytorch_amd import amp, launch, models
@@ -122,14 +137,21 @@ def run(args) -> None:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     use_gpu = args.device == "cuda"
     copy_stream = None
+    if args.share_gpu:
+        os.environ["DPA_SHARE_GPU"] = "1"
+    if args.comm == "peer":
+        os.environ["DPA_COMM"] = "peer"
+    elif args.comm in ("rccl", "auto"):
+        os.environ.pop("DPA_COMM", None)
     if use_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU")
-        if torch.cuda.device_count() <= local_rank:
+        dev_index = launch.device_index(local_rank)
+        if torch.cuda.device_count() <= dev_index:
             raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible"
                              % (rank, local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
         # the input copy stream is created first so it gets a hardware queue of its own (see data.prefetcher.copy_stream)
         from distributed_pytorch_amd.data.prefetcher import copy_stream as _copy_stream
 
@@ -194,8 +216,8 @@ def run(args) -> None:
 
         kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
         # Apex DDP (the reference's AMP script) does not re-broadcast BN buffers every forward
-        model = DistributedDataParallel(model, device_ids=[local_rank] if use_gpu else None,
-                                        broadcast_buffers=False, **kw)
+        model = DistributedDataParallel(model, device_ids=[device.index] if use_gpu else None,
+                                        broadcast_buffers=False, grad_wire=args.grad_wire, **kw)
     model.train()
 
     total = args.steps + args.warmup + 2
@@ -264,7 +286,7 @@ def run(args) -> None:
         _emit(json.dumps({
             "metric": "images/sec (whole job) %s %s training" % (
                 {"resnet50": "ResNet-50"}.get(args.arch, args.arch), "AMP" if args.dtype != "fp32" else "fp32"),
-            "value": round(ips, 2), "unit": "images/sec", "n_gpus": n_ranks if use_gpu else 0, "steps": args.steps,
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": (min(n_ranks, torch.cuda.device_count()) if args.share_gpu else n_ranks) if use_gpu else 0, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype,
@@ -272,7 +294,8 @@ def run(args) -> None:
             "final_loss": final_loss,
             "config": {"model": args.arch, "global_batch": args.batch_size * n_ranks,
                        "per_gpu_batch": args.batch_size, "seq_len": None, "image_size": args.image_size,
-                       "parallelism": "dp%d" % n_ranks + (" (forced DDP path)" if args.force_ddp and world == 1 else ""),
+                       "parallelism": "dp%d" % n_ranks + (" (forced DDP path)" if args.force_ddp and world == 1 else "")
+                                      + (" (ranks share one GPU)" if args.share_gpu and world > 1 else ""),
                        "ranks": n_ranks, "device": args.device,
                        "optimizer": "sgd+momentum+wd (fused)",
                        "amp": "O2 " + args.dtype if args.dtype != "fp32" else "O0",

@@ -56,8 +56,13 @@ def add_native_flags(parser: argparse.ArgumentParser) -> None:
                    help="capture the train step into a hipGraph (static shapes)")
     g.add_argument("--dist-timeout", default=600.0, type=float, metavar="SEC",
                    help="rendezvous / collective timeout")
-    g.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
-                   help="collective engine: native C++ RCCL reducer or torch.distributed")
+    g.add_argument("--comm", default="auto", choices=["auto", "native", "torch", "peer"],
+                   help="collective engine: native C++ reducer on RCCL, torch.distributed, or the peer-memory "
+                        "communicator (two-shot all-reduce over hipIpc windows, csrc/comm/peer.hip)")
+    g.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16", "fp16"],
+                   help="dtype fp32 gradient buckets travel in (auto: the AMP dtype under O2/O3, like Apex)")
+    g.add_argument("--share-gpu", action="store_true",
+                   help="local ranks wrap around the visible GPUs (rehearse N ranks on one device; needs --comm peer)")
     g.add_argument("--fault-inject", default=None, type=str, metavar="RANK:STEP",
                    help="test hook: hard-exit RANK at global STEP")
     g.add_argument("--out-dir", default="", type=str, help="where checkpoints/logs are written")

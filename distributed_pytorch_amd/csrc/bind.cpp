@@ -422,4 +422,5 @@ PYBIND11_MODULE(_C, m) {
   bind_comm(m);
   bind_store(m);
   bind_p2p(m);
+  bind_peer(m);
 }

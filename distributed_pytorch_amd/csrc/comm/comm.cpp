@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -40,6 +41,7 @@
 #include <utility>
 #include <vector>
 
+#include "../kernels/kernels.h"
 #include "host_backend.h"
 #include "reducer_core.h"
 
@@ -48,6 +50,7 @@ using dpa::comm::BucketReducerCore;
 using dpa::comm::HostBackend;
 using dpa::comm::OnTimeout;
 using dpa::comm::ReduceBackend;
+using dpa::comm::StreamCollective;
 using dpa::comm::dtype_bytes;
 
 namespace {
@@ -122,7 +125,7 @@ ncclDataType_t nccl_dtype(int code) {  // dpa::DType codes
     default: throw std::invalid_argument("unsupported comm dtype");
   }
 }
-class Communicator {
+class Communicator : public StreamCollective {
  public:
   Communicator(py::bytes id, int rank, int world, int device) : rank_(rank), world_(world), device_(device) {
     std::string s = id;
@@ -162,10 +165,39 @@ class Communicator {
       CHECK_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     }
   }
-  ~Communicator() {
+  ~Communicator() override {
     ncclComm_t c = comm_.exchange(nullptr);
     if (c) rccl().CommDestroy(c);
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (staging_) (void)hipFree(staging_);
+  }
+
+  // ---- StreamCollective: what the reducer's backend calls ------------------------------------------------------
+  // A narrowed wire format (fp32 gradients travelling as bf16 / fp16, what Apex O2 does with its fp16 gradients,
+  // imagenet_ddp_apex.py:169-183) is three enqueues on the communicator's stream: cast into the staging buffer,
+  // ncclAllReduce(avg) of the 16-bit values, cast back into the fp32 bucket.  The casts stream at HBM rate and sit
+  // behind backward like the collective itself; the links carry half the bytes.
+  void reserve_wire(size_t max_count, int dtype, int wire) override {
+    if (wire < 0 || wire == dtype) return;
+    const size_t need = max_count * dtype_bytes(wire);
+    if (need <= staging_bytes_) return;
+    CHECK_HIP(hipSetDevice(device_));
+    CHECK_HIP(hipStreamSynchronize(stream_));
+    if (staging_) CHECK_HIP(hipFree(staging_));
+    staging_ = nullptr;
+    CHECK_HIP(hipMalloc(&staging_, need));
+    staging_bytes_ = need;
+  }
+  void reduce_mean(uintptr_t p, size_t count, int dtype, int wire) override {
+    if (wire < 0 || wire == dtype) {
+      all_reduce(p, count, dtype, true, 0);
+      return;
+    }
+    if (count * dtype_bytes(wire) > staging_bytes_)
+      throw std::runtime_error("RCCL wire staging smaller than the slice (reserve_wire was not called)");
+    dpa::cast_launch(reinterpret_cast<const void*>(p), dtype, staging_, wire, (long)count, stream_);
+    all_reduce(reinterpret_cast<uintptr_t>(staging_), count, wire, true, 0);
+    dpa::cast_launch(staging_, wire, reinterpret_cast<void*>(p), dtype, (long)count, stream_);
   }
   static py::bytes unique_id() {
     ncclUniqueId uid;
@@ -184,34 +216,43 @@ class Communicator {
     return c;
   }
 
+  // Every enqueue holds `mu_` from the moment it loads the handle until RCCL has returned, and abort() takes the
+  // same lock before it invalidates the handle: the watchdog thread cannot destroy a communicator the training
+  // thread is about to pass to ncclAllReduce (c10d's ProcessGroupNCCL guards its communicators the same way).
+  // The lock is timed on the abort side only -- an enqueue wedged inside RCCL must not keep the abort out.
   void all_reduce(uintptr_t p, size_t count, int dtype, bool avg, uintptr_t s) {
+    std::lock_guard<std::timed_mutex> guard(mu_);
     check_nccl(rccl().AllReduce(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), count, nccl_dtype(dtype),
                                 avg ? ncclAvg : ncclSum, live(), pick(s)),
                "ncclAllReduce");
   }
   void all_reduce_max(uintptr_t p, size_t count, int dtype, uintptr_t s) {
+    std::lock_guard<std::timed_mutex> guard(mu_);
     check_nccl(rccl().AllReduce(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), count, nccl_dtype(dtype),
                                 ncclMax, live(), pick(s)),
                "ncclAllReduce");
   }
   void broadcast(uintptr_t p, size_t nbytes, int root, uintptr_t s) {
+    std::lock_guard<std::timed_mutex> guard(mu_);
     check_nccl(rccl().Broadcast(reinterpret_cast<void*>(p), reinterpret_cast<void*>(p), nbytes, ncclUint8, root, live(),
                                 pick(s)),
                "ncclBroadcast");
   }
   void all_gather(uintptr_t send, uintptr_t recv, size_t count, int dtype, uintptr_t s) {
+    std::lock_guard<std::timed_mutex> guard(mu_);
     check_nccl(rccl().AllGather(reinterpret_cast<void*>(send), reinterpret_cast<void*>(recv), count, nccl_dtype(dtype),
                                 live(), pick(s)),
                "ncclAllGather");
   }
   // ncclCommAbort: kernels of this communicator that are spinning on a dead peer exit, the streams drain.
   // Callable from any thread (the reducer's watchdog); the communicator is unusable afterwards.
-  void abort() {
+  void abort() override {
+    std::unique_lock<std::timed_mutex> guard(mu_, std::chrono::seconds(2));   // proceeds unlocked after 2 s
     ncclComm_t c = comm_.exchange(nullptr);
     if (c) rccl().CommAbort(c);
   }
-  bool aborted() const { return comm_.load() == nullptr; }
-  std::string async_error() {
+  bool aborted() const override { return comm_.load() == nullptr; }
+  std::string async_error() override {
     ncclComm_t c = comm_.load();
     if (!c) return "communicator aborted";
     ncclResult_t r = ncclSuccess;
@@ -234,10 +275,10 @@ class Communicator {
     CHECK_HIP(hipStreamSynchronize(stream_));
   }
   int rank() const { return rank_; }
-  int world() const { return world_; }
-  int device() const { return device_; }
+  int world() const override { return world_; }
+  int device() const override { return device_; }
   uintptr_t stream_handle() const { return reinterpret_cast<uintptr_t>(stream_); }
-  hipStream_t stream() const { return stream_; }
+  hipStream_t stream() const override { return stream_; }
 
  private:
   hipEvent_t scratch_event() {
@@ -251,18 +292,22 @@ class Communicator {
     return e;
   }
   std::atomic<ncclComm_t> comm_{nullptr};
+  std::timed_mutex mu_;
   hipStream_t stream_ = nullptr;
   int rank_, world_, device_;
   std::vector<hipEvent_t> events_;
   size_t next_event_ = 0;
+  void* staging_ = nullptr;         // 16-bit wire copy of the slice in flight (one at a time: one stream)
+  size_t staging_bytes_ = 0;
 };
 
 // The reducer's communication queue on a GPU: the communicator's HIP stream, HIP events as ready / done points,
-// one in-place ncclAllReduce(avg) per slice.  No host synchronisation anywhere -- the step stays asynchronous.
-class RcclBackend : public ReduceBackend {
+// one in-place mean all-reduce per slice (ncclAllReduce on RCCL, the two-shot window kernels on the peer
+// communicator).  No host synchronisation anywhere -- the step stays asynchronous.
+class StreamBackend : public ReduceBackend {
  public:
-  explicit RcclBackend(std::shared_ptr<Communicator> comm) : comm_(std::move(comm)) {}
-  ~RcclBackend() override {
+  explicit StreamBackend(std::shared_ptr<StreamCollective> comm) : comm_(std::move(comm)) {}
+  ~StreamBackend() override {
     for (hipEvent_t e : ready_) (void)hipEventDestroy(e);
     for (hipEvent_t e : done_) (void)hipEventDestroy(e);
   }
@@ -280,9 +325,10 @@ class RcclBackend : public ReduceBackend {
     CHECK_HIP(hipEventRecord(ready_.at(b), reinterpret_cast<hipStream_t>(compute_stream)));
     CHECK_HIP(hipStreamWaitEvent(comm_->stream(), ready_.at(b), 0));
   }
-  void launch(int, uintptr_t base, size_t offset_elems, size_t count, int dtype) override {
-    comm_->all_reduce(base + offset_elems * dtype_bytes(dtype), count, dtype, true, 0);
+  void launch(int, uintptr_t base, size_t offset_elems, size_t count, int dtype, int wire) override {
+    comm_->reduce_mean(base + offset_elems * dtype_bytes(dtype), count, dtype, wire);
   }
+  void reserve_wire(size_t max_count, int dtype, int wire) { comm_->reserve_wire(max_count, dtype, wire); }
   void record_done(int b) override { CHECK_HIP(hipEventRecord(done_.at(b), comm_->stream())); }
   void wait_done(int b, uintptr_t compute_stream) override {
     CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(compute_stream), done_.at(b), 0));
@@ -299,7 +345,7 @@ class RcclBackend : public ReduceBackend {
   void abort() override { comm_->abort(); }
 
  private:
-  std::shared_ptr<Communicator> comm_;
+  std::shared_ptr<StreamCollective> comm_;
   std::vector<hipEvent_t> ready_, done_;
 };
 
@@ -308,9 +354,25 @@ class PyReducer {
  public:
   PyReducer(std::shared_ptr<ReduceBackend> backend, std::vector<uintptr_t> ptrs, std::vector<size_t> counts,
             std::vector<int> dtypes, std::vector<int> param_bucket, size_t chunk_bytes, double timeout_s,
-            bool exit_on_timeout, double grace_s)
-      : core_(std::move(backend), std::move(ptrs), std::move(counts), std::move(dtypes), std::move(param_bucket),
-              chunk_bytes, timeout_s, exit_on_timeout ? OnTimeout::kExitProcess : OnTimeout::kFlagOnly, grace_s) {}
+            bool exit_on_timeout, double grace_s, int wire_dtype)
+      : core_(reserve(backend, counts, dtypes, chunk_bytes, wire_dtype), std::move(ptrs), std::move(counts),
+              std::move(dtypes), std::move(param_bucket), chunk_bytes, timeout_s,
+              exit_on_timeout ? OnTimeout::kExitProcess : OnTimeout::kFlagOnly, grace_s, wire_dtype) {}
+  // the staging of a narrowed wire format is sized for the largest slice before the first launch
+  static std::shared_ptr<ReduceBackend> reserve(std::shared_ptr<ReduceBackend> backend,
+                                                const std::vector<size_t>& counts, const std::vector<int>& dtypes,
+                                                size_t chunk_bytes, int wire) {
+    auto* sb = dynamic_cast<StreamBackend*>(backend.get());
+    if (sb && wire >= 0) {
+      for (size_t b = 0; b < counts.size() && b < dtypes.size(); ++b) {
+        if (dtypes[b] != 0 || wire == dtypes[b]) continue;
+        size_t n = counts[b];
+        if (chunk_bytes > 0) n = std::min(n, std::max<size_t>(1, chunk_bytes / dtype_bytes(dtypes[b])));
+        sb->reserve_wire(n, dtypes[b], wire);
+      }
+    }
+    return backend;
+  }
   void prepare() { core_.prepare(); }
   void mark_ready(int idx, uintptr_t s) { core_.mark_ready(idx, s); }
   void flush(uintptr_t s, bool force) { core_.flush(s, force); }
@@ -321,6 +383,7 @@ class PyReducer {
   int num_buckets() const { return core_.num_buckets(); }
   int launched() const { return core_.launched(); }
   long collectives() const { return core_.collectives(); }
+  long wire_bytes() const { return core_.wire_bytes(); }
   std::vector<int> observed_order() const { return core_.observed_order(); }
   bool failed() const { return core_.failed(); }
   std::string failure() const { return core_.failure(); }
@@ -334,11 +397,12 @@ class PyReducer {
 void bind_comm(py::module_& m) {
   m.def("plan_buckets", &dpa::comm::plan_buckets, py::arg("numels"), py::arg("elem_sizes"), py::arg("dtype_keys"),
         py::arg("order"), py::arg("cap_bytes"), py::arg("first_cap_bytes"), py::arg("align_bytes") = 256,
-        py::arg("last_cap_bytes") = 0);
+        py::arg("last_cap_bytes") = 0, py::arg("min_bytes") = 1L << 20);
   m.attr("WATCHDOG_EXIT_CODE") = (int)dpa::comm::kWatchdogExitCode;
   m.def("rccl_version", &Communicator::version);
   m.def("rccl_unique_id", &Communicator::unique_id);
-  py::class_<Communicator, std::shared_ptr<Communicator>>(m, "Communicator")
+  py::class_<StreamCollective, std::shared_ptr<StreamCollective>>(m, "StreamCollective");
+  py::class_<Communicator, StreamCollective, std::shared_ptr<Communicator>>(m, "Communicator")
       .def(py::init<py::bytes, int, int, int>(), py::arg("unique_id"), py::arg("rank"), py::arg("world_size"),
            py::arg("device"))
       .def("all_reduce", &Communicator::all_reduce, py::arg("ptr"), py::arg("count"), py::arg("dtype"),
@@ -359,8 +423,9 @@ void bind_comm(py::module_& m) {
       .def_property_readonly("world_size", &Communicator::world)
       .def_property_readonly("stream", &Communicator::stream_handle);
   py::class_<ReduceBackend, std::shared_ptr<ReduceBackend>>(m, "ReduceBackend");
-  py::class_<RcclBackend, ReduceBackend, std::shared_ptr<RcclBackend>>(m, "RcclBackend")
-      .def(py::init<std::shared_ptr<Communicator>>(), py::arg("comm"));
+  py::class_<StreamBackend, ReduceBackend, std::shared_ptr<StreamBackend>>(m, "StreamBackend")
+      .def(py::init<std::shared_ptr<StreamCollective>>(), py::arg("comm"));
+  m.attr("RcclBackend") = m.attr("StreamBackend");
   py::class_<HostBackend, ReduceBackend, std::shared_ptr<HostBackend>>(m, "HostBackend")
       .def(py::init([](const std::string& host, int port, int rank, int world, double timeout_s,
                        const std::string& tag) {
@@ -372,10 +437,10 @@ void bind_comm(py::module_& m) {
       .def_property_readonly("collectives", &HostBackend::collectives);
   py::class_<PyReducer>(m, "BucketReducer")
       .def(py::init<std::shared_ptr<ReduceBackend>, std::vector<uintptr_t>, std::vector<size_t>, std::vector<int>,
-                    std::vector<int>, size_t, double, bool, double>(),
+                    std::vector<int>, size_t, double, bool, double, int>(),
            py::arg("backend"), py::arg("bucket_ptrs"), py::arg("bucket_counts"), py::arg("bucket_dtypes"),
            py::arg("param_bucket"), py::arg("chunk_bytes") = (size_t)128 << 20, py::arg("timeout_s") = 0.0,
-           py::arg("exit_on_timeout") = true, py::arg("grace_s") = 10.0)
+           py::arg("exit_on_timeout") = true, py::arg("grace_s") = 10.0, py::arg("wire_dtype") = -1)
       .def("prepare", &PyReducer::prepare)
       .def("mark_ready", &PyReducer::mark_ready)
       .def("flush", &PyReducer::flush)
@@ -384,6 +449,7 @@ void bind_comm(py::module_& m) {
       .def_property_readonly("num_buckets", &PyReducer::num_buckets)
       .def_property_readonly("launched", &PyReducer::launched)
       .def_property_readonly("collectives", &PyReducer::collectives)
+      .def_property_readonly("wire_bytes", &PyReducer::wire_bytes)
       .def_property_readonly("failed", &PyReducer::failed)
       .def_property_readonly("failure", &PyReducer::failure);
 }

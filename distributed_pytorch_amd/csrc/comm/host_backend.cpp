@@ -47,18 +47,22 @@ void HostBackend::resize(int num_buckets) {
   done_.assign((size_t)num_buckets, 0);
 }
 
-void HostBackend::launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype) {
+void HostBackend::launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype, int wire) {
   const size_t esz = dtype_bytes(dtype);
   if (dtype != 0 && dtype != 1) throw std::invalid_argument("HostBackend: float32 / bfloat16 gradients only");
+  if (wire >= 0 && wire != dtype && !(dtype == 0 && wire == 1))
+    throw std::invalid_argument("HostBackend: the only narrowed wire format is bfloat16 for float32 gradients");
+  if (wire == dtype) wire = -1;
   std::lock_guard<std::mutex> lock(mu_);
-  queue_.push_back(Task{bucket, false, reinterpret_cast<char*>(base) + offset_elems * esz, count, dtype, seq_++});
+  queue_.push_back(Task{bucket, false, reinterpret_cast<char*>(base) + offset_elems * esz, count, dtype, wire,
+                        seq_++});
   cv_.notify_all();
 }
 
 void HostBackend::record_done(int bucket) {
   std::lock_guard<std::mutex> lock(mu_);
   issued_.at((size_t)bucket)++;
-  queue_.push_back(Task{bucket, true, nullptr, 0, 0, 0});
+  queue_.push_back(Task{bucket, true, nullptr, 0, 0, -1, 0});
   cv_.notify_all();
 }
 
@@ -89,15 +93,25 @@ void HostBackend::abort() {
 
 void HostBackend::reduce(const Task& t) {
   if (world_ == 1) return;
-  const size_t esz = dtype_bytes(t.dtype);
+  const bool narrow = t.wire == 1 && t.dtype == 0;      // fp32 storage, bf16 on the wire
+  const int wdt = narrow ? 1 : t.dtype;
+  const size_t esz = dtype_bytes(wdt);
   const std::string base = "hr/" + tag_ + "/" + std::to_string(t.seq);
-  std::string mine(static_cast<const char*>(t.ptr), t.count * esz);
+  std::string mine;
+  if (narrow) {
+    mine.resize(t.count * 2);
+    const float* src = static_cast<const float*>(t.ptr);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(&mine[0]);
+    for (size_t i = 0; i < t.count; ++i) dst[i] = float_to_bf16(src[i]);
+  } else {
+    mine.assign(static_cast<const char*>(t.ptr), t.count * esz);
+  }
   client_.set(base + "/" + std::to_string(rank_), mine);
   std::vector<double> acc(t.count, 0.0);
   for (int r = 0; r < world_; ++r) {           // rank order on every rank: bit-identical sums
     const std::string part = r == rank_ ? mine : client_.get(base + "/" + std::to_string(r));
     if (part.size() != t.count * esz) throw std::runtime_error("HostBackend: peer sent a different slice size");
-    if (t.dtype == 0) {
+    if (wdt == 0) {
       const float* p = reinterpret_cast<const float*>(part.data());
       for (size_t i = 0; i < t.count; ++i) acc[i] += (double)p[i];
     } else {
@@ -106,7 +120,10 @@ void HostBackend::reduce(const Task& t) {
     }
   }
   const double inv = 1.0 / world_;
-  if (t.dtype == 0) {
+  if (narrow) {        // the mean is rounded to the wire format once, like the GPU backends' gather phase delivers it
+    float* o = static_cast<float*>(t.ptr);
+    for (size_t i = 0; i < t.count; ++i) o[i] = bf16_to_float(float_to_bf16((float)(acc[i] * inv)));
+  } else if (t.dtype == 0) {
     float* o = static_cast<float*>(t.ptr);
     for (size_t i = 0; i < t.count; ++i) o[i] = (float)(acc[i] * inv);
   } else {

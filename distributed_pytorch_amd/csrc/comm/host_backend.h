@@ -27,7 +27,7 @@ class HostBackend : public ReduceBackend {
   ~HostBackend() override;
   int world() const override { return world_; }
   void record_ready(int, uintptr_t) override {}     // host memory: program order is the ordering
-  void launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype) override;
+  void launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype, int wire) override;
   void record_done(int bucket) override;
   void wait_done(int bucket, uintptr_t) override;
   bool query_done(int bucket) override;
@@ -43,6 +43,7 @@ class HostBackend : public ReduceBackend {
     void* ptr;
     size_t count;
     int dtype;
+    int wire;               // -1: travels as stored; 1: fp32 storage rounded to bf16 on the wire
     long seq;
   };
   void run();

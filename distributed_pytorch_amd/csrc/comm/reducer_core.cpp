@@ -25,9 +25,9 @@ size_t dtype_bytes(int code) {
 BucketReducerCore::BucketReducerCore(std::shared_ptr<ReduceBackend> backend, std::vector<uintptr_t> ptrs,
                                      std::vector<size_t> counts, std::vector<int> dtypes,
                                      std::vector<int> param_bucket, size_t chunk_bytes, double timeout_s,
-                                     OnTimeout on_timeout, double grace_s)
+                                     OnTimeout on_timeout, double grace_s, int wire_dtype)
     : backend_(std::move(backend)), param_bucket_(std::move(param_bucket)), chunk_bytes_(chunk_bytes),
-      timeout_s_(timeout_s), grace_s_(grace_s), on_timeout_(on_timeout) {
+      wire_(wire_dtype), timeout_s_(timeout_s), grace_s_(grace_s), on_timeout_(on_timeout) {
   if (!backend_) throw std::invalid_argument("reducer: no backend");
   if (ptrs.size() != counts.size() || ptrs.size() != dtypes.size()) throw std::invalid_argument("bucket arrays");
   buckets_.resize(ptrs.size());
@@ -95,9 +95,13 @@ void BucketReducerCore::launch_bucket(size_t b, uintptr_t /*compute_stream*/) {
   const size_t esz = dtype_bytes(k.dtype);
   size_t step = chunk_bytes_ > 0 ? std::max<size_t>(1, chunk_bytes_ / esz) : k.count;
   if (step >= k.count) step = k.count;
+  // only fp32 storage is narrowed on the wire; 16-bit buckets (O3) already travel as they are
+  const int wire = (wire_ >= 0 && k.dtype == 0 && wire_ != k.dtype) ? wire_ : -1;
   for (size_t off = 0; off < k.count; off += step) {
-    backend_->launch((int)b, k.ptr, off, std::min(step, k.count - off), k.dtype);
+    const size_t n = std::min(step, k.count - off);
+    backend_->launch((int)b, k.ptr, off, n, k.dtype, wire);
     ++collectives_;
+    wire_bytes_ += (long)(n * (wire >= 0 ? dtype_bytes(wire) : esz));
   }
   backend_->record_done((int)b);
   k.launched = true;
@@ -212,7 +216,7 @@ struct PlannedBucket {
 
 void plan_range(const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
                 const std::vector<long>& order, size_t begin, size_t end, long cap, long first_cap, long align,
-                std::vector<PlannedBucket>& out) {
+                long min_bytes, std::vector<PlannedBucket>& out) {
   std::vector<std::pair<long, int>> open;       // dtype -> index into out (few dtypes: linear search)
   std::vector<long> first_done;
   auto find_open = [&](long dk) -> int {
@@ -231,9 +235,12 @@ void plan_range(const std::vector<long>& numels, const std::vector<long>& esz, c
     }
     int& cur = open[slot].second;
     const long limit = done(dk) ? cap : first_cap;
+    // A bucket is closed when the next tensor would push it past the cap -- unless it is still tiny: a 16 KB bias
+    // in front of a 392 MiB weight would otherwise travel as a latency-bound collective of its own, queued in
+    // front of the big one (in-order issue).  Such a bucket takes the tensor anyway and is closed by the next.
     if (cur >= 0 && !out[cur].pids.empty() && out[cur].total * es + n * es > limit) {
       if (!done(dk)) first_done.push_back(dk);
-      cur = -1;
+      if (out[cur].total * es >= min_bytes) cur = -1;
     }
     if (cur < 0) {
       out.emplace_back();
@@ -252,7 +259,7 @@ void plan_range(const std::vector<long>& numels, const std::vector<long>& esz, c
 
 std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> plan_buckets(
     const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
-    const std::vector<long>& order, long cap, long first_cap, long align, long last_cap) {
+    const std::vector<long>& order, long cap, long first_cap, long align, long last_cap, long min_bytes) {
   if (numels.size() != esz.size() || numels.size() != dkeys.size())
     throw std::invalid_argument("plan_buckets: per-parameter lists differ in length");
   for (long pid : order)
@@ -272,9 +279,9 @@ std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> plan_b
     }
     if (split == 0) split = order.size();       // everything fits the tail: plan normally
   }
-  plan_range(numels, esz, dkeys, order, 0, split, cap, first_cap, align, out);
+  plan_range(numels, esz, dkeys, order, 0, split, cap, first_cap, align, min_bytes, out);
   const long inf = 1L << 62;
-  plan_range(numels, esz, dkeys, order, split, order.size(), inf, inf, align, out);
+  plan_range(numels, esz, dkeys, order, split, order.size(), inf, inf, align, min_bytes, out);
   std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> res;
   res.reserve(out.size());
   for (auto& b : out) res.emplace_back(b.dtype_key, std::move(b.pids), std::move(b.offsets), b.total);

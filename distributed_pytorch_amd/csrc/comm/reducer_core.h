@@ -43,8 +43,11 @@ class ReduceBackend {
   virtual int world() const = 0;
   // ordering point: everything enqueued on `compute_stream` so far precedes this bucket's collectives
   virtual void record_ready(int bucket, uintptr_t compute_stream) = 0;
-  // one in-place mean all-reduce of `count` elements at base + offset, behind the bucket's ready point
-  virtual void launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype) = 0;
+  // one in-place mean all-reduce of `count` elements at base + offset, behind the bucket's ready point.
+  // `wire` is the dtype code the values TRAVEL in (-1 or == dtype: as stored).  A 16-bit wire halves the bytes on
+  // the links (Apex O2 all-reduces fp16 gradients, imagenet_ddp_apex.py:169-183): the backend casts the slice on
+  // its own queue, reduces, and writes the result back in the storage dtype -- every rank ends with the same bits.
+  virtual void launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype, int wire) = 0;
   virtual void record_done(int bucket) = 0;
   // the compute queue (or the calling thread, for a host backend) waits for the bucket's done point
   virtual void wait_done(int bucket, uintptr_t compute_stream) = 0;
@@ -60,7 +63,7 @@ class BucketReducerCore {
  public:
   BucketReducerCore(std::shared_ptr<ReduceBackend> backend, std::vector<uintptr_t> ptrs, std::vector<size_t> counts,
                     std::vector<int> dtypes, std::vector<int> param_bucket, size_t chunk_bytes, double timeout_s,
-                    OnTimeout on_timeout = OnTimeout::kExitProcess, double grace_s = 10.0);
+                    OnTimeout on_timeout = OnTimeout::kExitProcess, double grace_s = 10.0, int wire_dtype = -1);
   ~BucketReducerCore();
 
   void prepare();
@@ -71,6 +74,8 @@ class BucketReducerCore {
   int num_buckets() const { return (int)buckets_.size(); }
   int launched() const { return launched_; }
   long collectives() const { return collectives_; }       // slices issued since construction
+  long wire_bytes() const { return wire_bytes_; }         // bytes handed to the links since construction
+  int wire_dtype() const { return wire_; }
   std::vector<int> observed_order() const { return observed_; }   // last complete iteration's ready order
   bool failed() const { return failed_.load(); }
   std::string failure() const;
@@ -97,6 +102,8 @@ class BucketReducerCore {
   size_t next_ = 0;
   int launched_ = 0;
   long collectives_ = 0;
+  long wire_bytes_ = 0;
+  int wire_ = -1;
 
   // watchdog state
   double timeout_s_, grace_s_;
@@ -113,11 +120,13 @@ class BucketReducerCore {
 // Packs parameters, given in expected gradient-ready order, into dtype-homogeneous flat buckets.  The first
 // bucket of each dtype is small (its all-reduce starts early), the parameters that become ready LAST form a
 // small bucket of their own (its all-reduce is the only one that cannot overlap with backward), everything
-// in between fills `cap` buckets sized for xGMI.  Every view offset is aligned to `align` bytes.
+// in between fills `cap` buckets sized for xGMI.  A bucket smaller than `min_bytes` is never closed: it takes the
+// next tensor even past the cap (no latency-bound collective for a lone bias).  Every view offset is aligned to
+// `align` bytes.
 // -> (dtype_key, param ids, element offsets, padded element total) per bucket
 std::vector<std::tuple<long, std::vector<long>, std::vector<long>, long>> plan_buckets(
     const std::vector<long>& numels, const std::vector<long>& esz, const std::vector<long>& dkeys,
-    const std::vector<long>& order, long cap, long first_cap, long align, long last_cap);
+    const std::vector<long>& order, long cap, long first_cap, long align, long last_cap, long min_bytes = 1L << 20);
 
 }  // namespace comm
 }  // namespace dpa

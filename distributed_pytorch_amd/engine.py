@@ -94,9 +94,14 @@ def main(args) -> None:
 def main_worker(local_rank: int, ngpus_per_node: int, args) -> None:
     use_gpu = torch.cuda.is_available() and not args.cpu
     script = args.script
+    if getattr(args, "share_gpu", False):
+        os.environ["DPA_SHARE_GPU"] = "1"
+    if getattr(args, "comm", "auto") == "peer":
+        os.environ["DPA_COMM"] = "peer"
     if use_gpu:
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        dev_index = launch.device_index(local_rank)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
         from .data.prefetcher import copy_stream
 
         copy_stream(device)       # first stream of the process: a hardware queue of its own for the input copies
@@ -161,8 +166,8 @@ def main_worker(local_rank: int, ngpus_per_node: int, args) -> None:
         from .parallel import DistributedDataParallel
 
         model = DistributedDataParallel(
-            model, device_ids=[local_rank] if use_gpu else None, bucket_cap_mb=args.bucket_mb,
-            delay_allreduce=args.delay_allreduce, comm=args.comm,
+            model, device_ids=[device.index] if use_gpu else None, bucket_cap_mb=args.bucket_mb,
+            delay_allreduce=args.delay_allreduce, comm=args.comm, grad_wire=getattr(args, "grad_wire", "auto"),
             broadcast_buffers=not args.no_broadcast_buffers and script != "apex")
         model.bind_optimizer(optimizer)
     criterion = CrossEntropyLoss().to(device)

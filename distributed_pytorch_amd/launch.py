@@ -33,6 +33,14 @@ def device_count() -> int:
     return torch.cuda.device_count()
 
 
+def device_index(local_rank: int) -> int:
+    """The device a local rank binds.  ``DPA_SHARE_GPU=1``: ranks wrap around the visible devices, so W ranks can
+    share one GPU (peer-memory communicator only: RCCL refuses two ranks on a device)."""
+    if os.environ.get("DPA_SHARE_GPU", "0") == "1":
+        return local_rank % max(1, torch.cuda.device_count())
+    return local_rank
+
+
 def resolve_backend(name: str, use_gpu: bool) -> str:
     name = (name or "nccl").lower()
     if name == "rccl":

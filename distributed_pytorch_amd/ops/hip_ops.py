@@ -738,6 +738,13 @@ def materialize(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def _is_relu_out(x) -> bool:
+    """x is still exactly what a convolution + ReLU of this module wrote: tagged, and not modified in place since
+    (a stale tag would mask the consumer's gradient with values the ReLU never produced)."""
+    tag = getattr(x, "_dpa_relu_out", None)
+    return tag is not None and tag is not False and x._version == tag
+
+
 def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input_grad, skip=False):
     grad_sink.note_use(weight, bias)
     axf = getattr(x, "_dpa_deferred_coef", None)
@@ -753,7 +760,7 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
             x, axf = materialize(x), None
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
                                     bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None), axf,
-                                    bool(getattr(x, "_dpa_relu_out", False)))
+                                    _is_relu_out(x))
     if alias is not None:
         # its gradient returns to _ConvFn.backward (and nowhere else): a BatchNorm that takes it as the residual may
         # hand back the UNMASKED gradient plus its ReLU bit mask instead of writing a masked copy
@@ -765,7 +772,9 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
                                      and x.shape[-1] == Cw_ and Cw_ % 64 == 0 and K_ % 32 == 0 and x.is_contiguous()
                                      and needs_input_grad)
     if relu:
-        y._dpa_relu_out = True      # a max-pool that consumes it may hand back an already masked gradient (_premasked)
+        # a max-pool / 3x3 conv that consumes it may hand back an already masked gradient (_premasked); the tag holds
+        # the tensor's version so an in-place edit between producer and consumer (y.sub_(1)) voids it
+        y._dpa_relu_out = y._version
     out = (y, stats) if want_stats else y
     return (out, alias) if skip else out
 
@@ -1424,14 +1433,19 @@ class _BNEvalFn(torch.autograd.Function):
         y = torch.empty_like(x)
         C().bn_apply(x.data_ptr(), _p(residual), y.data_ptr(), M, Cc, _dt(x), coef[0].data_ptr(),
                      coef[1].data_ptr(), (1 if relu else 0) | (4 if relu == 6 else 0), st)
-        ctx.save_for_backward(y if relu else None, coef)
-        ctx.cfg = (relu, residual is not None)
+        # fine-tuning with frozen statistics still trains gamma / beta (torch does): their gradients need x and the
+        # running moments in backward
+        affine = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        ctx.save_for_backward(y if relu else None, coef, x if affine else None,
+                              running_mean if affine else None, running_var if affine else None)
+        ctx.cfg = (relu, residual is not None, float(eps))
+        ctx.params = (weight, bias) if affine else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        y, coef = ctx.saved_tensors
-        relu, has_res = ctx.cfg
+        y, coef, x, rm, rv = ctx.saved_tensors
+        relu, has_res, eps = ctx.cfg
         dy = dy if dy.is_contiguous() else dy.contiguous()
         Cc = dy.shape[-1]
         M = dy.numel() // Cc
@@ -1440,9 +1454,26 @@ class _BNEvalFn(torch.autograd.Function):
             dym = torch.empty_like(dy)
             C().relu_bwd(y.data_ptr(), dy.data_ptr(), dym.data_ptr(), dy.numel(), _dt(dy), st)
             dy = dym * (y < 6) if relu == 6 else dym     # eval-mode backward (fine-tuning frozen BN) is not a hot path
-        dx = torch.empty_like(dy)
-        C().bn_apply(dy.data_ptr(), 0, dx.data_ptr(), M, Cc, _dt(dy), coef[0].data_ptr(), coef[2].data_ptr(), 0, st)
-        return dx, None, None, (dy if has_res else None), None, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            C().bn_apply(dy.data_ptr(), 0, dx.data_ptr(), M, Cc, _dt(dy), coef[0].data_ptr(), coef[2].data_ptr(), 0, st)
+        dgamma = dbeta = None
+        if ctx.params is not None and x is not None:
+            weight, bias = ctx.params
+            # dgamma = sum dy * (x - running_mean) * invstd, dbeta = sum dy: the training-mode reducer with the running
+            # moments as its (mean, invstd)
+            mom = torch.stack([_f32(rm), torch.rsqrt(_f32(rv) + eps)]).contiguous()
+            nblk = C().bn_partial_rows(M, Cc)
+            part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=dy.device)
+            C().bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), 0, M, Cc, _dt(x), mom[0].data_ptr(), mom[1].data_ptr(), 0,
+                              coef[0].data_ptr(), coef[1].data_ptr(), part.data_ptr(), nblk, st)
+            dg = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+            db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+            C().bn_bwd_finalize(part.data_ptr(), nblk, Cc, dg.data_ptr(), db.data_ptr(), st)
+            dgamma = _deliver(weight, dg.to(weight.dtype)) if ctx.needs_input_grad[1] else None
+            dbeta = _deliver(bias, db.to(bias.dtype)) if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None
 
 
 def _act_code(relu) -> int:
@@ -1485,6 +1516,8 @@ def batch_norm(x, weight, bias, running_mean, running_var, num_batches_tracked, 
         if not relu and residual is None:
             y._dpa_bn_plain = True      # activation-free BN output: as a residual its gradient may arrive unmasked + bit mask
         return y
+    if torch.is_grad_enabled():
+        grad_sink.note_use(weight, bias)
     if isinstance(relu, str):          # eval mode is not a hot path: BN from running statistics, then the activation kernel
         y = _BNEvalFn.apply(x, weight, bias, residual, running_mean, running_var, float(eps), 0)
         return activation(y, relu)
@@ -1535,7 +1568,7 @@ class _MaxPoolFn(torch.autograd.Function):
 
 
 def max_pool2d(x, k, s, p, ceil_mode=False):
-    relu_in = _POOL_PREMASK and getattr(x, "_dpa_relu_out", False) and torch.is_grad_enabled() and x.requires_grad
+    relu_in = _POOL_PREMASK and _is_relu_out(x) and torch.is_grad_enabled() and x.requires_grad
     return _MaxPoolFn.apply(x, tuple(k), tuple(s), tuple(p), bool(ceil_mode), bool(relu_in))
 
 

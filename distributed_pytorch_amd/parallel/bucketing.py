@@ -36,9 +36,12 @@ class BucketSpec:
 
 def plan_buckets(numels: Sequence[int], elem_sizes: Sequence[int], dtype_keys: Sequence[int],
                  order: Sequence[int], cap_bytes: int, first_cap_bytes: int,
-                 align_bytes: int = 256, last_cap_bytes: int = 0) -> List[BucketSpec]:
+                 align_bytes: int = 256, last_cap_bytes: int = 0, min_bytes: int = MiB) -> List[BucketSpec]:
     """``order`` = parameter indices in expected ready order.  Returns buckets in
     the order they are expected to complete.
+
+    ``min_bytes``: a bucket smaller than this is never closed by the cap -- it takes the next tensor anyway, so a
+    lone bias in front of an over-cap weight (VGG-16 ``fc6``) does not become a latency-bound collective of its own.
 
     ``last_cap_bytes`` > 0: the parameters that become ready LAST (the first layers) are kept out of the big
     buckets and form a final bucket of at most that size -- its all-reduce is the only one that cannot overlap
@@ -51,15 +54,16 @@ def plan_buckets(numels: Sequence[int], elem_sizes: Sequence[int], dtype_keys: S
         ext = None
     if ext is not None and hasattr(ext, "plan_buckets"):
         raw = ext.plan_buckets(list(numels), list(elem_sizes), list(dtype_keys), list(order),
-                               int(cap_bytes), int(first_cap_bytes), int(align_bytes), int(last_cap_bytes))
+                               int(cap_bytes), int(first_cap_bytes), int(align_bytes), int(last_cap_bytes),
+                               int(min_bytes))
         return [BucketSpec(i, dk, list(pids), list(offs), [numels[p] for p in pids], tot)
                 for i, (dk, pids, offs, tot) in enumerate(raw)]
     return plan_buckets_py(numels, elem_sizes, dtype_keys, order, cap_bytes, first_cap_bytes,
-                           align_bytes, last_cap_bytes)
+                           align_bytes, last_cap_bytes, min_bytes)
 
 
 def plan_buckets_py(numels, elem_sizes, dtype_keys, order, cap_bytes, first_cap_bytes,
-                    align_bytes: int = 256, last_cap_bytes: int = 0) -> List[BucketSpec]:
+                    align_bytes: int = 256, last_cap_bytes: int = 0, min_bytes: int = MiB) -> List[BucketSpec]:
     """Pure-Python oracle of the native planner (same result, used in tests and without ``_C``)."""
     order = list(order)
     if last_cap_bytes > 0 and len(order) > 1:
@@ -72,8 +76,9 @@ def plan_buckets_py(numels, elem_sizes, dtype_keys, order, cap_bytes, first_cap_
             split -= 1
         if split > 0:
             out = plan_buckets_py(numels, elem_sizes, dtype_keys, order[:split], cap_bytes, first_cap_bytes,
-                                  align_bytes)
-            out += plan_buckets_py(numels, elem_sizes, dtype_keys, order[split:], 1 << 62, 1 << 62, align_bytes)
+                                  align_bytes, 0, min_bytes)
+            out += plan_buckets_py(numels, elem_sizes, dtype_keys, order[split:], 1 << 62, 1 << 62, align_bytes,
+                                   0, min_bytes)
             for i, b in enumerate(out):
                 b.index = i
             return out
@@ -86,7 +91,8 @@ def plan_buckets_py(numels, elem_sizes, dtype_keys, order, cap_bytes, first_cap_
         cap = cap_bytes if first_done.get(dk) else first_cap_bytes
         if cur is not None and cur.total * es + n * es > cap and cur.param_ids:
             first_done[dk] = True
-            cur = None
+            if cur.total * es >= min_bytes:         # a tiny bucket takes the tensor anyway (see the docstring)
+                cur = None
         if cur is None:
             cur = BucketSpec(len(buckets), dk)
             buckets.append(cur)

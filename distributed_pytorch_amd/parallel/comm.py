@@ -70,6 +70,23 @@ def default_comm(kind: str = "auto", group=None):
     npg = pg.native()
     if npg is not None:                       # native process group: its communicators, nothing to negotiate
         return npg.gpu_comm if npg.gpu_comm is not None else npg.host_comm
+    import os
+
+    if kind == "peer" or (kind in ("auto", "native") and os.environ.get("DPA_COMM") == "peer"):
+        # peer-memory communicator over the torch process group's store (no torch collective is ever issued)
+        from .peer_comm import PeerNativeComm
+
+        store = dist.distributed_c10d._get_default_store()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        seq = [0]
+
+        def exchange(payload: bytes):
+            seq[0] += 1
+            base = "dpa/peer/x%d" % seq[0]
+            store.set("%s/%d" % (base, rank), payload)
+            return [payload if r == rank else bytes(store.get("%s/%d" % (base, r))) for r in range(world)]
+
+        return PeerNativeComm.build(rank, world, torch.cuda.current_device(), exchange)
     if kind in ("auto", "native"):
         try:
             from .native_comm import NativeComm

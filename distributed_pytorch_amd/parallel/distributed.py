@@ -27,6 +27,12 @@ Capability parity with what the reference gets from
   for Inception / GoogLeNet / DenseNet, whose registration order is not their backward order.
 * **Watchdog**: a bucket whose all-reduce does not complete within ``collective_timeout_s`` aborts the
   communicator (``ncclCommAbort``) and fails the rank, so the launcher tears the job down.
+* **Wire format** (``grad_wire``): fp32 gradient buckets may TRAVEL as bf16 / fp16 -- half the bytes on the xGMI
+  links, what Apex O2 does with its fp16 gradients (``imagenet_ddp_apex.py:169-183,380-381``).  The backward
+  kernels still accumulate and store fp32 in the bucket views; the communication backend casts each slice on its
+  own queue right before the collective, reduces 16-bit values (fp32 accumulation in the peer backend and on the
+  host), and writes the mean back as fp32, so the fused optimizer reads what it always read.  ``auto`` = the AMP
+  compute dtype under O2 / O3, fp32 otherwise.
 * ``delay_allreduce=True``: one flat bucket per dtype, reduced after backward (Apex mode).
 * Init: parameter-shape verification across ranks, then rank-0 broadcast of the flat parameter
   and buffer arenas (C-c); optional per-forward buffer broadcast (C-d, ``broadcast_buffers``).
@@ -48,6 +54,27 @@ from torch import nn
 from ..ops import grad_sink
 from .bucketing import MiB, BucketSpec, chunk_ranges, plan_buckets
 from .comm import TorchComm, default_comm
+
+
+_WIRE_CODE = {"fp32": -1, "float32": -1, "bf16": 1, "bfloat16": 1, "fp16": 2, "float16": 2}
+_WIRE_TORCH = {1: torch.bfloat16, 2: torch.float16}
+
+
+def resolve_grad_wire(name: str) -> int:
+    """``auto`` / ``fp32`` / ``bf16`` / ``fp16`` -> dtype code of the reducer's wire format (-1: as stored)."""
+    import os as _os
+
+    name = (_os.environ.get("DPA_GRAD_WIRE") or name or "auto").lower()
+    if name == "auto":
+        from .. import amp as _amp
+
+        st = _amp.state()
+        if st.enabled and st.opt_level in ("O2", "O3") and st.dtype in (torch.bfloat16, torch.float16):
+            return 1 if st.dtype == torch.bfloat16 else 2
+        return -1
+    if name not in _WIRE_CODE:
+        raise ValueError("grad_wire must be auto, fp32, bf16 or fp16 (got %r)" % name)
+    return _WIRE_CODE[name]
 
 
 def _param_view(flat: torch.Tensor, off: int, p: torch.Tensor) -> torch.Tensor:
@@ -75,7 +102,7 @@ class GradArena:
 
     def __init__(self, params: List[nn.Parameter], cap_bytes: int = 1 << 62, first_cap_bytes: int = 1 << 62,
                  order: Optional[List[int]] = None, single_bucket: bool = False, on_ready=None,
-                 last_cap_bytes: int = 0):
+                 last_cap_bytes: int = 0, min_bytes: int = MiB):
         self.params = list(params)
         self.epoch = 0
         n = len(self.params)
@@ -86,7 +113,8 @@ class GradArena:
             cap_bytes = first_cap_bytes = 1 << 62
             last_cap_bytes = 0
         specs = plan_buckets([p.numel() for p in self.params], [p.element_size() for p in self.params],
-                             keys, order, cap_bytes, first_cap_bytes, last_cap_bytes=last_cap_bytes)
+                             keys, order, cap_bytes, first_cap_bytes, last_cap_bytes=last_cap_bytes,
+                             min_bytes=min(min_bytes, cap_bytes // 4))
         self.buckets: List[_Bucket] = []
         self.bucket_of: Dict[int, int] = {}
         self.view_of: Dict[int, torch.Tensor] = {}
@@ -154,6 +182,11 @@ class GradArena:
             s.uses = 0
 
 
+class _Finished:
+    def wait(self):
+        return True
+
+
 class _PyReducer:
     """Python twin of the C++ BucketReducer over a TorchComm (gloo on CPU, ProcessGroupNCCL on GPU)."""
 
@@ -164,6 +197,7 @@ class _PyReducer:
         self._observed: List[int] = []
         self._seen = set()
         self.collectives = 0
+        self.wire_bytes = 0
 
     def prepare(self):
         for b in self.arena.buckets:
@@ -208,16 +242,28 @@ class _PyReducer:
         if nbytes > ddp.chunk_bytes:
             pieces = [b.flat[s:e] for s, e in chunk_ranges(b.flat.numel(), b.flat.element_size(), ddp.chunk_bytes)]
         self.collectives += len(pieces)
+        wire = _WIRE_TORCH.get(ddp.wire_code) if b.flat.dtype == torch.float32 else None
+        self.wire_bytes += sum(p.numel() * (2 if wire is not None else p.element_size()) for p in pieces)
         if ddp.on_gpu and ddp.comm_stream is not None:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(ddp.device))
             with torch.cuda.stream(ddp.comm_stream):
                 ddp.comm_stream.wait_event(ready)
                 for piece in pieces:
-                    b.work.append(ddp.comm.all_reduce_mean(piece, async_op=True))
+                    b.work.append(self._reduce_piece(piece, wire))
         else:
             for piece in pieces:
-                b.work.append(ddp.comm.all_reduce_mean(piece, async_op=True))
+                b.work.append(self._reduce_piece(piece, wire))
+
+    def _reduce_piece(self, piece: torch.Tensor, wire):
+        """One slice through the communicator; a narrowed wire format is cast -> all-reduce -> cast back."""
+        comm = self.ddp.comm
+        if wire is None:
+            return comm.all_reduce_mean(piece, async_op=True)
+        low = piece.to(wire)
+        comm.all_reduce_mean(low, async_op=False)
+        piece.copy_(low)
+        return _Finished()
 
     def finalize(self):
         self.flush(True)
@@ -239,7 +285,7 @@ class _NativeReducer:
         pb = [arena.bucket_of[i] for i in range(len(arena.params))]
         self.raw = ddp.comm.make_reducer(arena.flat_buffers(), pb, chunk_bytes=ddp.chunk_bytes,
                                          timeout_s=ddp.collective_timeout_s,
-                                         exit_on_timeout=ddp.exit_on_timeout)
+                                         exit_on_timeout=ddp.exit_on_timeout, wire_dtype=ddp.wire_code)
 
     def _stream(self) -> int:
         return torch.cuda.current_stream().cuda_stream if self.ddp.on_gpu else 0
@@ -262,6 +308,10 @@ class _NativeReducer:
     def collectives(self) -> int:
         return self.raw.collectives
 
+    @property
+    def wire_bytes(self) -> int:
+        return self.raw.wire_bytes
+
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
@@ -269,7 +319,7 @@ class DistributedDataParallel(nn.Module):
                  delay_allreduce: bool = False, broadcast_buffers: bool = True,
                  comm: str = "auto", chunk_mb: float = 128.0, verify_shapes: bool = True,
                  collective_timeout_s: Optional[float] = None, replan: bool = True,
-                 exit_on_timeout: bool = True):
+                 exit_on_timeout: bool = True, grad_wire: str = "auto", min_bucket_mb: float = 1.0):
         super().__init__()
         import os as _os
 
@@ -279,11 +329,13 @@ class DistributedDataParallel(nn.Module):
         self.cap_bytes = int(bucket_cap_mb * MiB)
         self.first_cap_bytes = int(first_bucket_mb * MiB)
         self.last_cap_bytes = int(last_bucket_mb * MiB)
+        self.min_bucket_bytes = int(min_bucket_mb * MiB)    # smaller buckets are folded into their neighbour
         self.chunk_bytes = int(float(_os.environ.get("DPA_CHUNK_MB", chunk_mb)) * MiB)
         if collective_timeout_s is None:
             collective_timeout_s = float(_os.environ.get("DPA_COLLECTIVE_TIMEOUT_S", "600"))
         self.collective_timeout_s = float(collective_timeout_s)
         self.exit_on_timeout = exit_on_timeout
+        self.wire_code = resolve_grad_wire(grad_wire)
         self._replan_state = "observe" if (replan and not delay_allreduce
                                            and _os.environ.get("DPA_REPLAN", "1") == "1") else "off"
         self._new_order: Optional[List[int]] = None
@@ -318,7 +370,7 @@ class DistributedDataParallel(nn.Module):
 
         self.arena = GradArena(self.params, self.cap_bytes, self.first_cap_bytes, order=order,
                                single_bucket=self.delay_allreduce, on_ready=self._on_sink_ready,
-                               last_cap_bytes=self.last_cap_bytes)
+                               last_cap_bytes=self.last_cap_bytes, min_bytes=self.min_bucket_bytes)
         force = _os.environ.get("DPA_FORCE_NATIVE_REDUCER", "0") == "1"     # world_size 1 test hook
         self.reducer = _NativeReducer(self, self.arena) if (self.native and (self.world_size > 1 or force)) \
             else _PyReducer(self, self.arena)
@@ -490,8 +542,12 @@ class DistributedDataParallel(nn.Module):
     def comm_summary(self) -> dict:
         """What the benchmark prints: how the gradients travel."""
         sizes = [b.flat.numel() * b.flat.element_size() for b in self.arena.buckets]
+        wire = sum(b.flat.numel() * (2 if (self.wire_code > 0 and b.flat.dtype == torch.float32)
+                                     else b.flat.element_size()) for b in self.arena.buckets)
         return {"backend": getattr(self.comm, "backend", "none") if self.comm is not None else "none",
                 "reducer": "c++" if isinstance(self.reducer, _NativeReducer) else "python",
                 "ranks": self.world_size, "buckets": len(sizes), "bucket_mbytes": [round(s / MiB, 1) for s in sizes],
-                "bytes_per_step": int(sum(sizes)), "chunk_mbytes": self.chunk_bytes / MiB,
-                "replanned": self.replans, "collectives": int(self.reducer.collectives)}
+                "grad_wire": {-1: "fp32", 1: "bf16", 2: "fp16"}[self.wire_code],
+                "bytes_per_step": int(wire), "bucket_bytes": int(sum(sizes)), "chunk_mbytes": self.chunk_bytes / MiB,
+                "replanned": self.replans, "collectives": int(self.reducer.collectives),
+                "wire_bytes_total": int(getattr(self.reducer, "wire_bytes", 0))}

@@ -192,7 +192,7 @@ class NativeComm:
     def _order_after_current(self) -> None:
         self.raw.comm_waits_for(torch.cuda.current_stream().cuda_stream)
 
-    def all_reduce_mean(self, flat: torch.Tensor, async_op: bool = True):
+    def all_reduce_mean(self, flat: torch.Tensor, async_op: bool = True, wire: int = -1):
         self._order_after_current()
         self.raw.all_reduce(flat.data_ptr(), flat.numel(), _DT[flat.dtype], True, 0)
         h = _StreamWait(self.raw)
@@ -241,9 +241,11 @@ class NativeComm:
         torch.cuda.current_stream().synchronize()
 
     def make_reducer(self, flats, param_bucket, chunk_bytes: int = 128 << 20, timeout_s: float = 0.0,
-                     exit_on_timeout: bool = True, grace_s: float = 10.0):
-        """The C++ BucketReducer on this communicator's stream (``csrc/comm/reducer_core.cpp`` + RcclBackend)."""
+                     exit_on_timeout: bool = True, grace_s: float = 10.0, wire_dtype: int = -1):
+        """The C++ BucketReducer on this communicator's stream (``csrc/comm/reducer_core.cpp`` + StreamBackend).
+        ``wire_dtype``: dtype code fp32 buckets travel in (1 bf16, 2 fp16, -1 as stored)."""
         ext = backend.require()
-        return ext.BucketReducer(ext.RcclBackend(self.raw), [f.data_ptr() for f in flats],
+        return ext.BucketReducer(ext.StreamBackend(self.raw), [f.data_ptr() for f in flats],
                                  [f.numel() for f in flats], [_DT[f.dtype] for f in flats], list(param_bucket),
-                                 int(chunk_bytes), float(timeout_s or 0.0), bool(exit_on_timeout), float(grace_s))
+                                 int(chunk_bytes), float(timeout_s or 0.0), bool(exit_on_timeout), float(grace_s),
+                                 int(wire_dtype))

@@ -114,7 +114,7 @@ class StoreComm:
         self.store.barrier("pg", self.world_size)
 
     def make_reducer(self, flats, param_bucket, chunk_bytes: int = 128 << 20, timeout_s: float = 0.0,
-                     exit_on_timeout: bool = True, grace_s: float = 10.0):
+                     exit_on_timeout: bool = True, grace_s: float = 10.0, wire_dtype: int = -1):
         """The C++ BucketReducer over host memory: the same state machine that drives RCCL on a GPU, with a
         worker thread + the TcpStore as its communication queue (``csrc/comm/host_backend.cpp``)."""
         from .. import backend as _backend
@@ -127,7 +127,7 @@ class StoreComm:
                              "g%d" % _REDUCER_GEN[0])
         return ext.BucketReducer(be, [f.data_ptr() for f in flats], [f.numel() for f in flats],
                                  [_HOST_DT[f.dtype] for f in flats], list(param_bucket), int(chunk_bytes),
-                                 float(timeout_s or 0.0), bool(exit_on_timeout), float(grace_s))
+                                 float(timeout_s or 0.0), bool(exit_on_timeout), float(grace_s), int(wire_dtype))
 
 
 _REDUCER_GEN = [0]      # reducers are built in the same order on every rank: the count names their store keys
@@ -179,7 +179,14 @@ class NativeProcessGroup:
         # census: fail early (with a timeout, not a hang) when a rank never shows up
         self.store.add("census", 1)
         self.store.barrier("init", self.world_size)
-        if use_gpu:
+        if use_gpu and os.environ.get("DPA_COMM", "auto") == "peer":
+            # peer-memory communicator (csrc/comm/peer.hip): hipIpc windows instead of RCCL -- also between ranks that
+            # share one device
+            from .peer_comm import PeerNativeComm
+
+            self.gpu_comm = PeerNativeComm.build(self.rank, self.world_size, torch.cuda.current_device(),
+                                                 self.host_comm._exchange)
+        elif use_gpu:
             from .native_comm import NativeComm
 
             # pre-flight: ncclCommInitRank blocks until EVERY rank calls it, so a rank that cannot even load RCCL (or

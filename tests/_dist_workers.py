@@ -190,7 +190,7 @@ class OutOfOrderNet(torch.nn.Module):
         return self.last(torch.relu(self.mid(torch.relu(self.first(x)))))
 
 
-def ddp_native_reducer(local_rank, world, port, out_dir):
+def ddp_native_reducer(local_rank, world, port, out_dir, wire="fp32"):
     """The C++ BucketReducer over the host backend (TcpStore + worker thread) at world >= 2: chunked buckets,
     re-planning from the observed ready order, an unused parameter, three optimizer steps."""
     from distributed_pytorch_amd.optim import FusedSGD
@@ -199,7 +199,7 @@ def ddp_native_reducer(local_rank, world, port, out_dir):
     _init(local_rank, world, port, "native")
     model = OutOfOrderNet()
     ddp = DistributedDataParallel(model, bucket_cap_mb=0.008, first_bucket_mb=0.001, last_bucket_mb=0.0,
-                                  chunk_mb=0.004, collective_timeout_s=30.0)
+                                  chunk_mb=0.004, collective_timeout_s=30.0, grad_wire=wire, min_bucket_mb=0.0)
     summary0 = ddp.comm_summary()
     plan0 = [list(b.spec.param_ids) for b in ddp.arena.buckets]
     opt = FusedSGD(ddp.parameters(), lr=0.05, momentum=0.9)

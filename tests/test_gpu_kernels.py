@@ -620,6 +620,31 @@ def test_relu_conv_maxpool_premasked_gradient(k, s, p, ceil, dtype):
     assert not hip_ops._premasked
 
 
+def test_relu_tag_is_void_after_an_in_place_edit_of_the_activation():
+    """The pre-masked fast paths trust a tag on the conv + ReLU output.  An in-place edit between the producer and the
+    pool voids it (the tag records the tensor's version): the pool must not mask with values the ReLU never produced.
+    Autograd then refuses the backward anyway (the convolution saved its output) -- never silently wrong gradients."""
+    from distributed_pytorch_amd.ops import hip_ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 8, 8, 32, device=DEV).bfloat16().requires_grad_(True)
+    w = (torch.randn(32, 32, 3, 3, device=DEV) / 17).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1, relu=True)
+    assert hip_ops._is_relu_out(y)
+    y.sub_(1.0)
+    assert not hip_ops._is_relu_out(y)
+    mod = hip_ops.C()
+    real, calls = mod.relu_bwd, []
+    mod.relu_bwd = lambda *a: (calls.append(a[3]), real(*a))[1]
+    try:
+        z = F.max_pool2d(y, 2, 2, 0)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            z.float().sum().backward()
+        assert calls == []                      # the pool did not take the pre-masked path
+    finally:
+        mod.relu_bwd = real
+        hip_ops._premasked.clear()
+
+
 @pytest.mark.parametrize("row3", [-1, 0])
 @pytest.mark.parametrize("cin,cmid,cout", [(32, 64, 128), (64, 128, 64), (64, 512, 64)])
 def test_relu_conv_conv_masked_data_gradient(cin, cmid, cout, row3):
