@@ -228,7 +228,7 @@ def run(args) -> None:
                            s2d=bool(getattr(base, "stem_s2d", False)) and use_gpu, stream=copy_stream)
 
     graphed = None
-    if args.graph and world == 1 and use_gpu:
+    if args.graph and use_gpu:
         from distributed_pytorch_amd.utils.graph import GraphedTrainStep
 
         graphed = GraphedTrainStep(model, opt, warmup=2)

@@ -387,6 +387,7 @@ class PyReducer {
   std::vector<int> observed_order() const { return core_.observed_order(); }
   bool failed() const { return core_.failed(); }
   std::string failure() const { return core_.failure(); }
+  void set_paused(bool on) { core_.set_paused(on); }
 
  private:
   BucketReducerCore core_;
@@ -446,6 +447,7 @@ void bind_comm(py::module_& m) {
       .def("flush", &PyReducer::flush)
       .def("finalize", &PyReducer::finalize)
       .def("observed_order", &PyReducer::observed_order)
+      .def("set_paused", &PyReducer::set_paused)
       .def_property_readonly("num_buckets", &PyReducer::num_buckets)
       .def_property_readonly("launched", &PyReducer::launched)
       .def_property_readonly("collectives", &PyReducer::collectives)

@@ -131,7 +131,9 @@ void BucketReducerCore::flush(uintptr_t compute_stream, bool force) {
 // end of backward: issue the stragglers and make the compute queue wait for every bucket
 void BucketReducerCore::finalize(uintptr_t compute_stream) {
   flush(compute_stream, true);
-  for (size_t b = 0; b < buckets_.size(); ++b) backend_->wait_done((int)b, compute_stream);
+  // buckets are issued in index order on ONE in-order queue: the last bucket's done point implies every earlier
+  // one (a cross-stream wait costs ~15 us of host time on HIP, and a dependency edge on the GPU, per call)
+  if (!buckets_.empty()) backend_->wait_done((int)buckets_.size() - 1, compute_stream);
   check_failed();
 }
 
@@ -160,6 +162,7 @@ void BucketReducerCore::watchdog() {
          slept += std::chrono::milliseconds(10))
       std::this_thread::sleep_for(std::chrono::milliseconds(10));
     if (stop_.load()) break;
+    if (paused_.load()) continue;
     std::unique_lock<std::mutex> lock(mu_);
     std::string why;
     const auto now = Clock::now();

@@ -78,6 +78,9 @@ class BucketReducerCore {
   int wire_dtype() const { return wire_; }
   std::vector<int> observed_order() const { return observed_; }   // last complete iteration's ready order
   bool failed() const { return failed_.load(); }
+  // the watchdog must not query events while a hipGraph capture is recording them (an illegal call there can
+  // invalidate the capture); paused, it only sleeps
+  void set_paused(bool on) { paused_.store(on); }
   std::string failure() const;
 
  private:
@@ -111,7 +114,7 @@ class BucketReducerCore {
   mutable std::mutex mu_;
   std::vector<char> inflight_;
   std::vector<std::chrono::steady_clock::time_point> since_;
-  std::atomic<bool> failed_{false}, acked_{false}, stop_{false};
+  std::atomic<bool> failed_{false}, acked_{false}, stop_{false}, paused_{false};
   std::string failure_;
   std::thread thread_;
 };

@@ -288,12 +288,13 @@ class _Run:
         self.jsonl = None
         self.graphed = None
         if getattr(args, "hip_graph", False):
-            if device.type == "cuda" and world == 1:
+            if device.type == "cuda":
+                # with DDP the reducer's communication stream is captured as a fork / join of the same graph
                 from .utils.graph import GraphedTrainStep
 
                 self.graphed = GraphedTrainStep(model, optimizer)
             elif is_main:
-                print("=> --hip-graph applies to single-process GPU runs; this run executes eagerly")
+                print("=> --hip-graph applies to GPU runs; this run executes eagerly")
         if is_main and args.out_dir:
             os.makedirs(args.out_dir, exist_ok=True)
             self.jsonl = open(os.path.join(args.out_dir, "metrics.jsonl"), "a")

@@ -304,6 +304,9 @@ class _NativeReducer:
     def observed_order(self) -> List[int]:
         return list(self.raw.observed_order())
 
+    def set_paused(self, on: bool) -> None:
+        self.raw.set_paused(bool(on))
+
     @property
     def collectives(self) -> int:
         return self.raw.collectives
@@ -357,7 +360,9 @@ class DistributedDataParallel(nn.Module):
             if verify_shapes:
                 self._verify_shapes()
             self._sync_module_states()
-        self._buffer_arena()
+        self._buf_flat: List[torch.Tensor] = []
+        if broadcast_buffers:               # the flat buffer arena only exists to make the per-forward broadcast cheap
+            self._buffer_arena()
         self._callback_queued = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._order = list(range(len(self.params) - 1, -1, -1))     # reverse registration order until observed
@@ -524,6 +529,25 @@ class DistributedDataParallel(nn.Module):
         self.reducer.prepare()
         if self._replan_state == "observe" and self.require_backward_grad_sync:
             self._observe_order()
+
+    # ------------------------------------------------------------------ hipGraph capture (utils/graph.py)
+    def graph_ready(self) -> bool:
+        """True once nothing about the step can change any more: buckets re-planned, arena final."""
+        return self._new_order is None and self._replan_state in ("done", "off")
+
+    def capture_begin(self) -> None:
+        """The step is about to be recorded into a hipGraph.  The reducer's event hand-off (ready event on the
+        capturing stream -> communication stream waits -> collectives -> done event -> capturing stream waits) is
+        exactly a capture fork / join, so the communication stream's kernels become nodes of the same graph; the
+        watchdog thread pauses, because querying an event that is being captured is illegal."""
+        pause = getattr(self.reducer, "set_paused", None)
+        if pause is not None:
+            pause(True)
+
+    def capture_end(self) -> None:
+        pause = getattr(self.reducer, "set_paused", None)
+        if pause is not None:
+            pause(False)
 
     # ------------------------------------------------------------------ conveniences
     def zero_grad(self, set_to_none: bool = False) -> None:

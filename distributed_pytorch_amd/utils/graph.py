@@ -10,8 +10,15 @@ is captured ONCE into a HIP graph (``torch.cuda.CUDAGraph`` == hipGraph on ROCm;
 on torch's current stream, so stream capture records them like any ATen kernel) and replayed per step
 with the batch copied into static input buffers.  Host-side values that change between steps (learning
 rate, momentum, ...) live in a small device array that is refreshed BEFORE the replay, so schedules keep
-working.  Single-process only: RCCL collectives on the reducer's side stream are not captured (DDP runs
-eagerly), and any capture failure falls back to eager execution with a warning.
+working.  Any capture failure falls back to eager execution with a warning.
+
+With DistributedDataParallel the gradient all-reduce is captured too: the reducer orders its communication stream
+behind a "ready" event recorded on the capturing stream and the capturing stream behind the last bucket's "done"
+event -- a capture fork / join -- so the collectives of the communication stream (the peer backend's pack /
+barrier / reduce / gather kernels, whose barrier sequence numbers are counted on the device; RCCL's kernels, which
+are capturable) become nodes of the same graph and still overlap with backward when it is replayed.  Capture starts
+only after the buckets have been re-planned (step 2) and every rank agrees that its capture succeeded; otherwise all
+ranks run eagerly.
 
 The reference has no equivalent (``cudnn.benchmark`` autotuning is its only launch-side knob,
 nd_imagenet.py:200, imagenet_ddp_apex.py:110) -- SURVEY.md section 7 "HIP streams and graphs".
@@ -83,10 +90,38 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         if self.stream is None:
             self.stream = torch.cuda.Stream(images.device)
-        with torch.cuda.graph(g, stream=self.stream):
-            loss, rec = self._step(self.static_x, self.static_t)
+        begin, end = getattr(self.model, "capture_begin", None), getattr(self.model, "capture_end", None)
+        err = None
+        if begin is not None:
+            begin()
+        try:
+            # thread_local: threads that are not part of the step (a communication library's progress thread) may
+            # keep calling into the runtime while the step is recorded
+            mode = "thread_local" if self._world() > 1 else "global"
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
+                loss, rec = self._step(self.static_x, self.static_t)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        finally:
+            if end is not None:
+                end()
+        if not self._all_ranks_ok(err is None, images.device):
+            raise err if err is not None else RuntimeError("capture failed on another rank")
         self.graph, self.loss, self.rec = g, loss, rec
         self.key = self._key(images, target)
+
+    def _world(self) -> int:
+        return int(getattr(self.model, "world_size", 1)) if hasattr(self.model, "comm_summary") else 1
+
+    def _all_ranks_ok(self, ok: bool, device) -> bool:
+        """Collective: every rank replays a graph or none does (a mixed job would deadlock in its first all-reduce)."""
+        if self._world() <= 1:
+            return ok
+        from ..parallel import process_group as pg
+
+        flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float32, device=device)
+        pg.all_reduce_sum(flag)
+        return float(flag.item()) == 0.0
 
     @staticmethod
     def _key(images, target):
@@ -101,7 +136,8 @@ class GraphedTrainStep:
             if key != self._seen_key:
                 self._seen_key, self._seen = key, 0
             self._seen += 1
-            if self._seen <= self.warmup:
+            ready = getattr(self.model, "graph_ready", None)
+            if self._seen <= self.warmup or (ready is not None and not ready()):
                 return self._on_side_stream(images, target)
             try:
                 self._capture(images, target)

@@ -216,3 +216,42 @@ def peer_hang(local_rank, world, port):
     ddp(x).sum().backward()                  # rank 0: the barrier times out on the device, the watchdog fails the rank
     torch.cuda.synchronize()
     time.sleep(90)
+
+
+def ddp_graph(local_rank, world, port, out_dir):
+    """--hip-graph with DDP at W > 1: the captured step (forward, backward, per-bucket peer all-reduce on the
+    communication stream, fused SGD) must reproduce the eager losses, and every rank must stay bit-identical."""
+    from distributed_pytorch_amd import amp
+    from distributed_pytorch_amd.optim import FusedSGD
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+    from distributed_pytorch_amd.parallel import process_group as pg
+    from distributed_pytorch_amd.utils.graph import GraphedTrainStep
+
+    _init(local_rank, world, port, window_mb=16)
+    out = {}
+    g = torch.Generator().manual_seed(123)
+    per = 8
+    x = torch.randint(0, 256, (8, per * world, 64, 64, 3), dtype=torch.uint8, generator=g)
+    t = torch.randint(0, 10, (8, per * world), generator=g)
+    for mode in ("eager", "graph"):
+        amp.state().reset()
+        model = _small_resnet().cuda().train()
+        opt = FusedSGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        model, opt = amp.initialize(model, opt, opt_level="O2", dtype="bf16")
+        ddp = DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=8.0, first_bucket_mb=0.5,
+                                      last_bucket_mb=0.25, broadcast_buffers=False, collective_timeout_s=60.0)
+        step = GraphedTrainStep(ddp, opt, warmup=2, enabled=(mode == "graph"))
+        losses = []
+        for it in range(8):
+            xs = x[it, local_rank * per:(local_rank + 1) * per].cuda()
+            ts = t[it, local_rank * per:(local_rank + 1) * per].cuda()
+            loss, _ = step(xs, ts)
+            losses.append(float(loss.detach().float().item()))
+        torch.cuda.synchronize()
+        pg.check_health()
+        out[mode] = {"losses": losses, "replays": step.replays,
+                     "params": {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()},
+                     "collectives": int(ddp.reducer.collectives)}
+        del step, ddp, opt, model
+    torch.save(out, os.path.join(out_dir, "rank%d.pt" % local_rank))
+    _finish()

@@ -278,6 +278,23 @@ def test_gpu_syncbn_over_peer_backend_equals_batchnorm_on_the_global_batch(tmp_p
     assert torch.allclose(sum(r["db"] for r in rs), bn.bias.grad.cpu(), rtol=1e-3, atol=1e-3)
 
 
+def test_hip_graph_captures_the_ddp_step_with_its_all_reduce(tmp_path):
+    """--hip-graph together with DDP (W = 2 sharing the GPU): the reducer's communication stream is captured as a fork
+    / join of the step's graph.  Replayed losses == eager losses, ranks bit-identical, the graph really replayed."""
+    import _gpu_dist_workers as G
+
+    world = 2
+    _spawn_shared(G.ddp_graph, world, (str(tmp_path),))
+    rs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(world)]
+    for r in rs:
+        assert r["graph"]["replays"] >= 5 and r["eager"]["replays"] == 0, (r["graph"]["replays"],)
+        for a, b in zip(r["eager"]["losses"], r["graph"]["losses"]):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (r["eager"]["losses"], r["graph"]["losses"])
+    for n in rs[0]["graph"]["params"]:
+        assert torch.equal(rs[0]["graph"]["params"][n], rs[1]["graph"]["params"][n]), n
+        assert torch.allclose(rs[0]["graph"]["params"][n], rs[0]["eager"]["params"][n], rtol=5e-2, atol=5e-3), n
+
+
 def test_dead_peer_ends_the_gpu_job_through_the_barrier_deadline_and_the_watchdog():
     """A rank that stops calling all-reduce: the survivor's barrier kernel gives up after DPA_PEER_TIMEOUT_S, the
     watchdog turns the communicator's error into exit code 86 and the supervisor tears the job down."""
