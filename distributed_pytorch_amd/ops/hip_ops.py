@@ -2196,7 +2196,7 @@ _GEMM8 = int(os.environ.get("DPA_GEMM8", "1"))      # 256x256 multi-phase GEMM: 
 
 def _gemm8_wins(M: int, N: int, K: int, dtype, out_dtype) -> bool:
     """The 256x256 multi-phase kernel (csrc/kernels/gemm8.hip) against the lean 128-row GEMM, measured on one MI355X
-    (scratch/gemm8_check.py -> profiles/r2/gemm8_vs_lean.txt): it needs a long K loop to amortise its pipeline fill
+    (bench/experiments/gemm8_check.py -> profiles/r2/gemm8_vs_lean.txt): it needs a long K loop to amortise its pipeline fill
     (1.1 PFLOP/s at 4096^3, 870 vs 708 TFLOP/s at 25216 x 3072 x 768) and a tile count that fills whole rounds of
     the 256 CUs (25216 x 768: 296 tiles = 2 rounds at 58 % -> the lean kernel wins there)."""
     if _GEMM8 == 0 or dtype == torch.float32 or out_dtype != dtype or K % 64 or N % 8:
