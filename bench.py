@@ -165,15 +165,24 @@ def run(args) -> None:
     backend = None
     # A rendezvous / communicator build that never returns (a rank that died before joining, a wedged collective) must
     # end the job with a message instead of hanging the launcher: hard exit after DPA_BENCH_INIT_TIMEOUT_S.
+    # The limit is re-armed per phase (rendezvous + wrap, then warm-up), and the extension is loaded before the clock
+    # starts, so a cold build cache or a slow architecture at a large batch does not count against it.
     init_done = threading.Event()
+    phase = {"name": "process-group / model set-up", "deadline": None}
+    if use_gpu:
+        from distributed_pytorch_amd import backend as _backend
+
+        _backend.require()
     if ddp:
         limit = float(os.environ.get("DPA_BENCH_INIT_TIMEOUT_S", "600"))
+        phase["deadline"] = time.monotonic() + limit
 
         def _init_watchdog():
-            if not init_done.wait(limit):
-                print("bench.py: rank %d: process-group / model set-up did not finish within %.0f s -- aborting"
-                      % (rank, limit), file=sys.stderr, flush=True)
-                os._exit(3)
+            while not init_done.wait(1.0):
+                if time.monotonic() > phase["deadline"]:
+                    print("bench.py: rank %d: %s did not finish within %.0f s -- aborting"
+                          % (rank, phase["name"], limit), file=sys.stderr, flush=True)
+                    os._exit(3)
 
         threading.Thread(target=_init_watchdog, daemon=True).start()
     if ddp:
@@ -217,8 +226,11 @@ def run(args) -> None:
         kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
         # Apex DDP (the reference's AMP script) does not re-broadcast BN buffers every forward
         model = DistributedDataParallel(model, device_ids=[device.index] if use_gpu else None,
-                                        broadcast_buffers=False, grad_wire=args.grad_wire, **kw)
+                                        broadcast_buffers=False, grad_wire=args.grad_wire,
+                                        probe=True if (args.force_ddp and world == 1) else None, **kw)
     model.train()
+    if ddp:
+        phase["name"], phase["deadline"] = "warm-up (first collectives)", time.monotonic() + limit
 
     total = args.steps + args.warmup + 2
     data = SyntheticImageNet(args.batch_size, world_size=world, rank=rank, image_size=args.image_size,
@@ -255,6 +267,8 @@ def run(args) -> None:
 
     for _ in range(args.warmup):
         loss = step()
+    if ddp:
+        model.finish_diagnosis()       # no time stamps (host waits) inside the timed region
     fence()
     init_done.set()
     t0 = time.perf_counter()
@@ -282,6 +296,8 @@ def run(args) -> None:
 
             comm["rccl_version"] = int(_be.require().rccl_version())
         comm["cpu_affinity"] = len(cpus)
+        comm["nccl_env"] = {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO",
+                                                           "NCCL_PROTO") if os.environ.get(k) is not None}
     if rank == 0:
         _emit(json.dumps({
             "metric": "images/sec (whole job) %s %s training" % (

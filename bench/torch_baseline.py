@@ -8,7 +8,7 @@ Same workload as bench.py: ResNet-50 (torchvision v1.5 definition, re-stated her
 installed), synthetic uint8 224x224 batches from pinned host memory normalised on the GPU, forward + loss +
 zero_grad + backward + SGD step in the timed region, images/sec = batch * steps / time.
 
-    python bench/torch_baseline.py --batch-size 256 --steps 20 --warmup 5 [--fp32] [--foreach 0]
+    python bench/torch_baseline.py [--arch resnet50|vgg16|alexnet] --batch-size 256 --steps 20 --warmup 5 [--fp32] [--foreach 0]
 """
 import argparse
 import json
@@ -65,8 +65,54 @@ class ResNet50(nn.Module):
         return self.fc(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
 
 
+class VGG16(nn.Module):
+    """torchvision vgg16 (configuration D, no BatchNorm): 138,357,544 parameters."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        layers, cin = [], 3
+        for v in (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"):
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d(7)
+        self.classifier = nn.Sequential(nn.Linear(512 * 49, 4096), nn.ReLU(True), nn.Dropout(),
+                                        nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(),
+                                        nn.Linear(4096, num_classes))
+
+    def forward(self, x):
+        return self.classifier(torch.flatten(self.avgpool(self.features(x)), 1))
+
+
+class AlexNet(nn.Module):
+    """torchvision alexnet: 61,100,840 parameters."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        self.features = nn.Sequential(
+            nn.Conv2d(3, 64, 11, 4, 2), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(64, 192, 5, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(192, 384, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(384, 256, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2))
+        self.avgpool = nn.AdaptiveAvgPool2d(6)
+        self.classifier = nn.Sequential(nn.Dropout(), nn.Linear(256 * 36, 4096), nn.ReLU(True),
+                                        nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(True),
+                                        nn.Linear(4096, num_classes))
+
+    def forward(self, x):
+        return self.classifier(torch.flatten(self.avgpool(self.features(x)), 1))
+
+
+ARCHS = {"resnet50": (ResNet50, 25557032), "vgg16": (VGG16, 138357544), "alexnet": (AlexNet, 61100840)}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="resnet50", choices=sorted(ARCHS))
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -87,8 +133,9 @@ def main():
     dev = torch.device("cuda", 0)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)       # the reference sets this (imagenet_ddp.py:158)
     torch.manual_seed(1234)
-    model = ResNet50().to(dev).to(memory_format=torch.channels_last).train()
-    assert sum(p.numel() for p in model.parameters()) == 25557032
+    ctor, nparams = ARCHS[args.arch]
+    model = ctor().to(dev).to(memory_format=torch.channels_last).train()
+    assert sum(p.numel() for p in model.parameters()) == nparams
     lr = 0.1 * args.batch_size / 256.0 * 0.01
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, foreach=bool(args.foreach))
     crit = nn.CrossEntropyLoss()
@@ -134,11 +181,11 @@ def main():
     dt = time.perf_counter() - t0
     progress["done"] = True
     print(json.dumps({
-        "metric": "images/sec ResNet-50 training, STOCK PyTorch-ROCm (torch.nn + autocast + channels_last + torch.optim.SGD)",
+        "metric": "images/sec " + args.arch + " training, STOCK PyTorch-ROCm (torch.nn + autocast + channels_last + torch.optim.SGD)",
         "value": round(args.batch_size * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
         "dtype": "fp32" if args.fp32 else "bf16 autocast", "final_loss": float(loss.item()),
-        "config": {"model": "resnet50", "per_gpu_batch": args.batch_size, "torch": torch.__version__,
+        "config": {"model": args.arch, "per_gpu_batch": args.batch_size, "torch": torch.__version__,
                    "foreach_sgd": bool(args.foreach), "miopen_benchmark": bool(args.miopen_benchmark),
                    "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}}), flush=True)
 

@@ -307,19 +307,52 @@ class Communicator : public StreamCollective {
 class StreamBackend : public ReduceBackend {
  public:
   explicit StreamBackend(std::shared_ptr<StreamCollective> comm) : comm_(std::move(comm)) {}
-  ~StreamBackend() override {
-    for (hipEvent_t e : ready_) (void)hipEventDestroy(e);
-    for (hipEvent_t e : done_) (void)hipEventDestroy(e);
-  }
+  ~StreamBackend() override { drop_events(); }
   int world() const override { return comm_->world(); }
   void resize(int n) override {
+    const unsigned flags = timing_ ? hipEventDefault : hipEventDisableTiming;
     while ((int)ready_.size() < n) {
       hipEvent_t r, d;
-      CHECK_HIP(hipEventCreateWithFlags(&r, hipEventDisableTiming));
-      CHECK_HIP(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+      CHECK_HIP(hipEventCreateWithFlags(&r, flags));
+      CHECK_HIP(hipEventCreateWithFlags(&d, flags));
       ready_.push_back(r);
       done_.push_back(d);
     }
+  }
+  // Timing swaps every event for one that carries a time stamp (and back).  Called between steps only: nothing
+  // recorded on the old events is waited for any more once the compute stream has joined the last bucket.
+  bool set_timing(bool on) override {
+    if (on == timing_) return true;
+    CHECK_HIP(hipSetDevice(comm_->device()));
+    CHECK_HIP(hipStreamSynchronize(comm_->stream()));
+    const int n = (int)ready_.size();
+    drop_events();
+    timing_ = on;
+    resize(n);
+    if (on) CHECK_HIP(hipEventCreateWithFlags(&tail_, hipEventDefault));
+    return true;
+  }
+  void mark_tail(uintptr_t compute_stream) override {
+    if (timing_ && tail_) CHECK_HIP(hipEventRecord(tail_, reinterpret_cast<hipStream_t>(compute_stream)));
+  }
+  std::vector<double> bucket_timings(int n) override {
+    std::vector<double> out;
+    if (!timing_ || !tail_ || n <= 0 || n > (int)done_.size()) return out;
+    CHECK_HIP(hipEventSynchronize(done_.at(n - 1)));
+    CHECK_HIP(hipEventSynchronize(tail_));
+    for (int b = 0; b < n; ++b) {
+      float busy = 0.f, exposed = 0.f;
+      if (hipEventElapsedTime(&busy, ready_.at(b), done_.at(b)) != hipSuccess) busy = -1.f;
+      // HIP reports stop-before-start as an error or as a negative span depending on the runtime: try both orders
+      if (hipEventElapsedTime(&exposed, tail_, done_.at(b)) != hipSuccess) {
+        float back = 0.f;
+        exposed = hipEventElapsedTime(&back, done_.at(b), tail_) == hipSuccess ? -back : 0.f;
+      }
+      (void)hipGetLastError();
+      out.push_back(busy);
+      out.push_back(exposed);
+    }
+    return out;
   }
   void record_ready(int b, uintptr_t compute_stream) override {
     CHECK_HIP(hipEventRecord(ready_.at(b), reinterpret_cast<hipStream_t>(compute_stream)));
@@ -345,8 +378,18 @@ class StreamBackend : public ReduceBackend {
   void abort() override { comm_->abort(); }
 
  private:
+  void drop_events() {
+    for (hipEvent_t e : ready_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : done_) (void)hipEventDestroy(e);
+    if (tail_) (void)hipEventDestroy(tail_);
+    ready_.clear();
+    done_.clear();
+    tail_ = nullptr;
+  }
   std::shared_ptr<StreamCollective> comm_;
   std::vector<hipEvent_t> ready_, done_;
+  hipEvent_t tail_ = nullptr;
+  bool timing_ = false;
 };
 
 // Python handle of the reducer (either backend).  `stream` arguments are hipStream_t integers (0 on the host).
@@ -388,6 +431,11 @@ class PyReducer {
   bool failed() const { return core_.failed(); }
   std::string failure() const { return core_.failure(); }
   void set_paused(bool on) { core_.set_paused(on); }
+  bool set_timing(bool on) { return core_.set_timing(on); }
+  std::vector<double> bucket_timings() {
+    py::gil_scoped_release nogil;
+    return core_.bucket_timings();
+  }
 
  private:
   BucketReducerCore core_;
@@ -448,6 +496,8 @@ void bind_comm(py::module_& m) {
       .def("finalize", &PyReducer::finalize)
       .def("observed_order", &PyReducer::observed_order)
       .def("set_paused", &PyReducer::set_paused)
+      .def("set_timing", &PyReducer::set_timing)
+      .def("bucket_timings", &PyReducer::bucket_timings)
       .def_property_readonly("num_buckets", &PyReducer::num_buckets)
       .def_property_readonly("launched", &PyReducer::launched)
       .def_property_readonly("collectives", &PyReducer::collectives)

@@ -45,6 +45,38 @@ void HostBackend::resize(int num_buckets) {
   std::lock_guard<std::mutex> lock(mu_);
   issued_.assign((size_t)num_buckets, 0);
   done_.assign((size_t)num_buckets, 0);
+  t_ready_.assign((size_t)num_buckets, Stamp());
+  t_done_.assign((size_t)num_buckets, Stamp());
+}
+
+void HostBackend::record_ready(int bucket, uintptr_t) {
+  std::lock_guard<std::mutex> lock(mu_);
+  if (timing_) t_ready_.at((size_t)bucket) = std::chrono::steady_clock::now();
+}
+
+bool HostBackend::set_timing(bool on) {
+  std::lock_guard<std::mutex> lock(mu_);
+  timing_ = on;
+  return true;
+}
+
+void HostBackend::mark_tail(uintptr_t) {
+  std::lock_guard<std::mutex> lock(mu_);
+  if (timing_) t_tail_ = std::chrono::steady_clock::now();
+}
+
+std::vector<double> HostBackend::bucket_timings(int n) {
+  std::vector<double> out;
+  if (n <= 0) return out;
+  wait_done(n - 1, 0);
+  std::lock_guard<std::mutex> lock(mu_);
+  if (!timing_ || (size_t)n > t_done_.size()) return out;
+  auto ms = [](Stamp a, Stamp b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  for (int b = 0; b < n; ++b) {
+    out.push_back(ms(t_ready_[(size_t)b], t_done_[(size_t)b]));
+    out.push_back(ms(t_tail_, t_done_[(size_t)b]));
+  }
+  return out;
 }
 
 void HostBackend::launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype, int wire) {
@@ -147,6 +179,7 @@ void HostBackend::run() {
       queue_.pop_front();
       if (t.marker) {
         done_.at((size_t)t.bucket)++;
+        if (timing_) t_done_.at((size_t)t.bucket) = std::chrono::steady_clock::now();
         cv_.notify_all();
         continue;
       }

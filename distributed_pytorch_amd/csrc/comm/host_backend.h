@@ -6,6 +6,7 @@
 // plumbing configuration (BASELINE config #1) and the way the C++ reducer is exercised at world sizes the
 // one-GPU test box cannot offer; gradients of a real job travel over RCCL (comm.cpp).
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -26,7 +27,7 @@ class HostBackend : public ReduceBackend {
   HostBackend(const std::string& host, int port, int rank, int world, double timeout_s, const std::string& tag);
   ~HostBackend() override;
   int world() const override { return world_; }
-  void record_ready(int, uintptr_t) override {}     // host memory: program order is the ordering
+  void record_ready(int bucket, uintptr_t) override;   // host memory: program order is the ordering (time stamp only)
   void launch(int bucket, uintptr_t base, size_t offset_elems, size_t count, int dtype, int wire) override;
   void record_done(int bucket) override;
   void wait_done(int bucket, uintptr_t) override;
@@ -34,6 +35,9 @@ class HostBackend : public ReduceBackend {
   std::string async_error() override;
   void abort() override;
   void resize(int num_buckets) override;
+  bool set_timing(bool on) override;
+  void mark_tail(uintptr_t) override;
+  std::vector<double> bucket_timings(int num_buckets) override;
   long collectives() const { return seq_; }
 
  private:
@@ -57,7 +61,10 @@ class HostBackend : public ReduceBackend {
   std::condition_variable cv_;
   std::deque<Task> queue_;
   std::vector<long> issued_, done_;     // done markers per bucket: issued vs retired
-  bool stop_ = false, aborted_ = false;
+  bool stop_ = false, aborted_ = false, timing_ = false;
+  using Stamp = std::chrono::steady_clock::time_point;
+  std::vector<Stamp> t_ready_, t_done_;  // host clock at the ready point / when the worker retired the done marker
+  Stamp t_tail_;
   std::string error_;
   std::thread thread_;
 };

@@ -131,6 +131,7 @@ void BucketReducerCore::flush(uintptr_t compute_stream, bool force) {
 // end of backward: issue the stragglers and make the compute queue wait for every bucket
 void BucketReducerCore::finalize(uintptr_t compute_stream) {
   flush(compute_stream, true);
+  backend_->mark_tail(compute_stream);      // (no-op unless the backend is timing this step)
   // buckets are issued in index order on ONE in-order queue: the last bucket's done point implies every earlier
   // one (a cross-stream wait costs ~15 us of host time on HIP, and a dependency edge on the GPU, per call)
   if (!buckets_.empty()) backend_->wait_done((int)buckets_.size() - 1, compute_stream);

@@ -55,6 +55,14 @@ class ReduceBackend {
   virtual std::string async_error() = 0;      // "" while healthy, watchdog thread
   virtual void abort() = 0;                   // any thread: unblocks everything in flight
   virtual void resize(int num_buckets) = 0;
+  // ---- self-diagnosis (optional; default: not supported).  With timing on, the ready / done points carry time
+  // stamps and finalize() marks the end of backward on the compute queue, so a step can report, per bucket, how long
+  // its collectives took behind the ready point and how much of that stuck out past the last backward kernel.
+  virtual bool set_timing(bool /*on*/) { return false; }
+  virtual void mark_tail(uintptr_t /*compute_stream*/) {}
+  // blocks until the last issued bucket is done; 2 values per bucket in milliseconds: (ready -> done,
+  // end of backward -> done; negative = finished that long BEFORE backward ended, i.e. fully hidden)
+  virtual std::vector<double> bucket_timings(int /*num_buckets*/) { return {}; }
 };
 
 enum class OnTimeout : int { kExitProcess = 0, kFlagOnly = 1 };
@@ -81,6 +89,8 @@ class BucketReducerCore {
   // the watchdog must not query events while a hipGraph capture is recording them (an illegal call there can
   // invalidate the capture); paused, it only sleeps
   void set_paused(bool on) { paused_.store(on); }
+  bool set_timing(bool on) { return backend_->set_timing(on); }
+  std::vector<double> bucket_timings() { return backend_->bucket_timings((int)buckets_.size()); }
   std::string failure() const;
 
  private:

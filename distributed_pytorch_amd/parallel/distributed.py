@@ -33,6 +33,11 @@ Capability parity with what the reference gets from
   own queue right before the collective, reduces 16-bit values (fp32 accumulation in the peer backend and on the
   host), and writes the mean back as fp32, so the fused optimizer reads what it always read.  ``auto`` = the AMP
   compute dtype under O2 / O3, fp32 otherwise.
+* **Self-diagnosis** (``comm_probe`` / ``comm_timing``): at construction with more than one rank the wrapper times a
+  64 MiB and a 16 MiB all-reduce (3 repetitions each) and keeps algorithm / bus bandwidth; once the buckets are final
+  it time-stamps the ready / done points of synchronised steps 3-6 and reports, per bucket, how long its
+  collectives ran and how much of that stuck out past the last backward kernel (the exposed wait).  Rank 0 prints
+  one line; ``comm_summary()`` carries both, so the first run on a real 8-GPU node explains itself.
 * ``delay_allreduce=True``: one flat bucket per dtype, reduced after backward (Apex mode).
 * Init: parameter-shape verification across ranks, then rank-0 broadcast of the flat parameter
   and buffer arenas (C-c); optional per-forward buffer broadcast (C-d, ``broadcast_buffers``).
@@ -198,6 +203,41 @@ class _PyReducer:
         self._seen = set()
         self.collectives = 0
         self.wire_bytes = 0
+        self.timing = False
+        self._t_ready: Dict[int, object] = {}
+        self._t_done: Dict[int, object] = {}
+        self._t_tail = None
+
+    # ---- self-diagnosis: same contract as the C++ reducer (ready -> done, end of backward -> done; milliseconds)
+    def set_timing(self, on: bool) -> bool:
+        self.timing = bool(on)
+        self._t_ready, self._t_done, self._t_tail = {}, {}, None
+        return True
+
+    def _stamp(self, stream=None):
+        import time as _time
+
+        if self.ddp.on_gpu:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream if stream is not None else torch.cuda.current_stream(self.ddp.device))
+            return e
+        return _time.perf_counter()
+
+    def bucket_timings(self) -> List[float]:
+        if not self.timing or self._t_tail is None:
+            return []
+        out: List[float] = []
+        if self.ddp.on_gpu:
+            torch.cuda.synchronize(self.ddp.device)
+        for i in range(len(self.arena.buckets)):
+            r, d = self._t_ready.get(i), self._t_done.get(i)
+            if r is None or d is None:
+                out += [0.0, 0.0]
+            elif self.ddp.on_gpu:
+                out += [float(r.elapsed_time(d)), float(self._t_tail.elapsed_time(d))]
+            else:
+                out += [(d - r) * 1e3, (d - self._t_tail) * 1e3]
+        return out
 
     def prepare(self):
         for b in self.arena.buckets:
@@ -237,6 +277,9 @@ class _PyReducer:
         ddp = self.ddp
         if ddp.world_size == 1:
             return
+        idx = self.next
+        if self.timing:
+            self._t_ready[idx] = self._stamp()
         nbytes = b.flat.numel() * b.flat.element_size()
         pieces = [b.flat]
         if nbytes > ddp.chunk_bytes:
@@ -251,9 +294,13 @@ class _PyReducer:
                 ddp.comm_stream.wait_event(ready)
                 for piece in pieces:
                     b.work.append(self._reduce_piece(piece, wire))
+                if self.timing:
+                    self._t_done[idx] = self._stamp(ddp.comm_stream)
         else:
             for piece in pieces:
                 b.work.append(self._reduce_piece(piece, wire))
+            if self.timing and ddp.on_gpu:
+                self._t_done[idx] = self._stamp()
 
     def _reduce_piece(self, piece: torch.Tensor, wire):
         """One slice through the communicator; a narrowed wire format is cast -> all-reduce -> cast back."""
@@ -267,9 +314,13 @@ class _PyReducer:
 
     def finalize(self):
         self.flush(True)
-        for b in self.arena.buckets:
+        if self.timing:
+            self._t_tail = self._stamp()
+        for i, b in enumerate(self.arena.buckets):
             for w in b.work:
                 w.wait()                        # GPU: stream-level wait; gloo: host wait
+            if self.timing and not self.ddp.on_gpu and b.launched and self.ddp.world_size > 1:
+                self._t_done[i] = self._stamp()
             b.work = []
         ddp = self.ddp
         if ddp.on_gpu and ddp.world_size > 1 and ddp.comm_stream is not None:
@@ -307,6 +358,12 @@ class _NativeReducer:
     def set_paused(self, on: bool) -> None:
         self.raw.set_paused(bool(on))
 
+    def set_timing(self, on: bool) -> bool:
+        return bool(self.raw.set_timing(bool(on)))
+
+    def bucket_timings(self) -> List[float]:
+        return [float(v) for v in self.raw.bucket_timings()]
+
     @property
     def collectives(self) -> int:
         return self.raw.collectives
@@ -322,7 +379,8 @@ class DistributedDataParallel(nn.Module):
                  delay_allreduce: bool = False, broadcast_buffers: bool = True,
                  comm: str = "auto", chunk_mb: float = 128.0, verify_shapes: bool = True,
                  collective_timeout_s: Optional[float] = None, replan: bool = True,
-                 exit_on_timeout: bool = True, grad_wire: str = "auto", min_bucket_mb: float = 1.0):
+                 exit_on_timeout: bool = True, grad_wire: str = "auto", min_bucket_mb: float = 1.0,
+                 probe: Optional[bool] = None):
         super().__init__()
         import os as _os
 
@@ -360,6 +418,17 @@ class DistributedDataParallel(nn.Module):
             if verify_shapes:
                 self._verify_shapes()
             self._sync_module_states()
+        # self-diagnosis (see the module docstring); DPA_COMM_PROBE=0 / 1 overrides (1 also probes a 1-rank group)
+        env_probe = _os.environ.get("DPA_COMM_PROBE")
+        self._probe_on = (probe if probe is not None else (self.world_size > 1 and self.on_gpu)) \
+            if env_probe is None else env_probe == "1"
+        self.comm_probe: Optional[dict] = None
+        self.comm_timing: Optional[dict] = None
+        self._timing_state = "wait" if self._probe_on else "off"
+        self._steady_steps = 0
+        self._timing_rows: List[List[float]] = []
+        if self._probe_on and self.comm is not None:
+            self._probe_links()
         self._buf_flat: List[torch.Tensor] = []
         if broadcast_buffers:               # the flat buffer arena only exists to make the per-forward broadcast cheap
             self._buffer_arena()
@@ -412,6 +481,90 @@ class DistributedDataParallel(nn.Module):
         self._order = order
         self._build_arena(order)
         self.replans += 1
+
+    # ------------------------------------------------------------------ self-diagnosis
+    def _probe_links(self, sizes_mb=(64, 16), reps: int = 3) -> None:
+        """Times in-place mean all-reduces of ``sizes_mb`` MiB (fp32) through the job's communicator: one untimed
+        call, then ``reps`` back to back between two synchronisation points.  algbw = bytes / time, busbw = algbw *
+        2 (W - 1) / W (the bytes every link-end really moves in a ring or a two-shot exchange) -- what the bucket
+        cap and the RCCL channel count should be judged against."""
+        import os as _os
+        import time as _time
+
+        scale = float(_os.environ.get("DPA_COMM_PROBE_SCALE", "1"))      # tests shrink the payload
+        w = self.world_size
+        rows = []
+        for mb in sizes_mb:
+            n = max(1024, int(mb * scale * MiB) // 4)
+            buf = torch.zeros(n, dtype=torch.float32, device=self.device)
+
+            def sync():
+                if self.on_gpu:
+                    torch.cuda.synchronize(self.device)
+
+            self.comm.all_reduce_mean(buf, async_op=False)
+            sync()
+            t0 = _time.perf_counter()
+            for _ in range(reps):
+                h = self.comm.all_reduce_mean(buf, async_op=False)
+                if h is not None and hasattr(h, "wait"):
+                    h.wait()
+            sync()
+            dt = (_time.perf_counter() - t0) / reps
+            alg = n * 4 / dt / 1e9
+            rows.append({"mbytes": round(n * 4 / MiB, 3), "ms": round(dt * 1e3, 3), "algbw_gbs": round(alg, 4),
+                         "busbw_gbs": round(alg * 2 * (w - 1) / max(w, 1), 4)})
+            del buf
+        self.comm_probe = {"ranks": w, "reps": reps, "all_reduce": rows,
+                           "env": {k: _os.environ[k] for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO",
+                                                               "NCCL_PROTO", "RCCL_MSCCL_ENABLE", "DPA_COMM")
+                                   if k in _os.environ}}
+        if self.comm.rank == 0:
+            print("[dpa ddp] link probe (%d ranks, %s): %s" % (
+                w, getattr(self.comm, "backend", "?"),
+                ", ".join("%g MiB %.3f ms = %.1f GB/s alg / %.1f GB/s bus" % (
+                    r["mbytes"], r["ms"], r["algbw_gbs"], r["busbw_gbs"]) for r in rows)), flush=True)
+
+    def _timing_tick(self) -> None:
+        """End of a synchronised backward.  Steps 2..5 after the buckets became final are time-stamped (each costs one
+        host wait for the step's last bucket; ``finish_diagnosis()`` ends the window early, e.g. before a timed run)."""
+        if self._timing_state in ("off", "done") or not self.graph_ready():
+            return
+        red = self.reducer
+        if not hasattr(red, "set_timing"):
+            self._timing_state = "off"
+            return
+        self._steady_steps += 1
+        if self._timing_state == "wait":
+            if self._steady_steps >= 1:                     # stamps start with the NEXT step
+                self._timing_state = "on" if red.set_timing(True) else "off"
+            return
+        row = red.bucket_timings()                          # blocks until this step's last bucket is done
+        if row:
+            self._timing_rows.append(row)
+        if self._steady_steps >= 5:
+            self._finish_timing()
+
+    def finish_diagnosis(self) -> None:
+        """Stop time-stamping now and report what was collected (idempotent)."""
+        if self._timing_state in ("wait", "on"):
+            self._finish_timing()
+
+    def _finish_timing(self) -> None:
+        if self._timing_state == "on":
+            self.reducer.set_timing(False)
+        self._timing_state = "done"
+        rows = self._timing_rows
+        if not rows:
+            return
+        nb = len(rows[0]) // 2
+        busy = [round(sum(r[2 * b] for r in rows) / len(rows), 3) for b in range(nb)]
+        exposed = [round(sum(r[2 * b + 1] for r in rows) / len(rows), 3) for b in range(nb)]
+        self.comm_timing = {"steps": len(rows), "bucket_busy_ms": busy, "bucket_exposed_ms": exposed,
+                            "exposed_tail_ms": round(max(0.0, max(exposed)), 3)}
+        if self.comm is None or self.comm.rank == 0:
+            print("[dpa ddp] buckets over %d steps: ready->done ms %s; past end of backward ms %s (negative = hidden)"
+                  % (len(rows), busy, exposed), flush=True)
 
     # ------------------------------------------------------------------ init-time sync
     def _verify_shapes(self) -> None:
@@ -526,6 +679,8 @@ class DistributedDataParallel(nn.Module):
         self._callback_queued = False
         self.arena.finish_step()
         self.reducer.finalize()
+        if self.require_backward_grad_sync:
+            self._timing_tick()
         self.reducer.prepare()
         if self._replan_state == "observe" and self.require_backward_grad_sync:
             self._observe_order()
@@ -540,6 +695,8 @@ class DistributedDataParallel(nn.Module):
         capturing stream -> communication stream waits -> collectives -> done event -> capturing stream waits) is
         exactly a capture fork / join, so the communication stream's kernels become nodes of the same graph; the
         watchdog thread pauses, because querying an event that is being captured is illegal."""
+        if self._timing_state in ("wait", "on"):        # an event query inside a capture is illegal: stop stamping
+            self._finish_timing()
         pause = getattr(self.reducer, "set_paused", None)
         if pause is not None:
             pause(True)
@@ -574,4 +731,5 @@ class DistributedDataParallel(nn.Module):
                 "grad_wire": {-1: "fp32", 1: "bf16", 2: "fp16"}[self.wire_code],
                 "bytes_per_step": int(wire), "bucket_bytes": int(sum(sizes)), "chunk_mbytes": self.chunk_bytes / MiB,
                 "replanned": self.replans, "collectives": int(self.reducer.collectives),
-                "wire_bytes_total": int(getattr(self.reducer, "wire_bytes", 0))}
+                "wire_bytes_total": int(getattr(self.reducer, "wire_bytes", 0)),
+                "probe": self.comm_probe, "timing": self.comm_timing}

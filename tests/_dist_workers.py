@@ -239,3 +239,24 @@ def reducer_hang(local_rank, world, port):
         return
     ddp(x).sum().backward()                  # rank 0: blocks in finalize until the watchdog fires
     time.sleep(60)
+
+
+def ddp_self_diagnosis(local_rank, world, port, out_dir, backend="native"):
+    """Link probe at construction + per-bucket ready->done / exposed-wait stamps of steady steps (both reducers)."""
+    from distributed_pytorch_amd.parallel import DistributedDataParallel
+
+    os.environ["DPA_COMM_PROBE"] = "1"
+    os.environ["DPA_COMM_PROBE_SCALE"] = "0.002"          # 128 KiB and 32 KiB instead of 64 / 16 MiB
+    _init(local_rank, world, port, backend)
+    model = OutOfOrderNet()
+    ddp = DistributedDataParallel(model, bucket_cap_mb=0.008, first_bucket_mb=0.001, last_bucket_mb=0.0,
+                                  collective_timeout_s=30.0, min_bucket_mb=0.0)
+    x = torch.randn(4, 20)
+    states = []
+    for _ in range(8):
+        ddp.zero_grad()
+        ddp(x).sum().backward()
+        states.append(ddp._timing_state)
+    torch.save({"summary": ddp.comm_summary(), "states": states, "buckets": len(ddp.arena.buckets)},
+               os.path.join(out_dir, "rank%d.pt" % local_rank))
+    _finish()

@@ -181,6 +181,25 @@ def test_bf16_gradient_wire_halves_the_bytes_and_tracks_the_fp32_trajectory(tmp_
         assert torch.allclose(fb["params"][n], fa["params"][n], rtol=2e-2, atol=2e-3), n
 
 
+@pytest.mark.parametrize("backend", ["native", "gloo"])
+def test_ddp_self_diagnosis_reports_link_probe_and_bucket_waits(tmp_path, backend):
+    """The comm layer explains itself: all-reduce bandwidth at construction, then per-bucket busy / exposed time of
+    the first steady steps, through the C++ reducer (host backend) and the Python reducer (gloo)."""
+    launch.spawn(W.ddp_self_diagnosis, 2, (2, _port(), str(tmp_path), backend))
+    for r in range(2):
+        d = torch.load(tmp_path / ("rank%d.pt" % r), weights_only=True)
+        probe, timing = d["summary"]["probe"], d["summary"]["timing"]
+        assert probe["ranks"] == 2 and len(probe["all_reduce"]) == 2
+        for row in probe["all_reduce"]:
+            assert row["ms"] > 0 and row["algbw_gbs"] > 0 and abs(row["busbw_gbs"] - row["algbw_gbs"]) < 1e-3
+        assert probe["all_reduce"][0]["mbytes"] > probe["all_reduce"][1]["mbytes"]
+        assert timing is not None and timing["steps"] == 4
+        assert len(timing["bucket_busy_ms"]) == len(timing["bucket_exposed_ms"]) == d["buckets"]
+        assert all(v >= 0 for v in timing["bucket_busy_ms"]) and timing["exposed_tail_ms"] >= 0
+        # stamps ran for a bounded window and were switched off again
+        assert d["states"][0] == "wait" and d["states"][-1] == "done" and "on" in d["states"]
+
+
 def test_watchdog_fails_the_rank_when_a_peer_stops_calling_all_reduce():
     t0 = time.time()
     with pytest.raises(launch.ProcessFailure) as e:
