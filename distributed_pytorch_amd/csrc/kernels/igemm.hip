@@ -1277,6 +1277,7 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     p.bn_z = nullptr;
   }
   t_xmask_done = false;
+  if (g_force_cfg < 0 && conv8_try(p, dtype, out_dtype, stream)) return;
   if (!(p.flags & kIgemmXMask) && (p.flags & kIgemmDense1) && g_force_cfg < 0 && gemm_lean_try(p, dtype, out_dtype, stream)) {
     DPA_CHECK_HIP(hipGetLastError());
     return;

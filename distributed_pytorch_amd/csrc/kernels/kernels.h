@@ -78,6 +78,14 @@ extern int g_stream_grid;
 void set_stream_grid(int blocks);
 void set_nt_mask(int mask);   // 1 BN apply, 2 BN backward apply, 4 BN backward reduce, 8 igemm output stores
 int igemm_num_configs();
+// conv8.hip: the 256 x 256 multi-phase pipeline with an implicit-GEMM front end, fused epilogues and a stream-K
+// schedule; takes stride-1 "same" 16-bit launches it covers and expects to win, false = run the other kernels.
+bool conv8_covers(const IgemmParams& p, int dtype, int out_dtype);
+bool conv8_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
+void conv8_set_mode(int mode);    // -1 automatic, 0 never, 1 / 2 always data-parallel / stream-K (when covered), 3 automatic + stream-K
+void conv8_set_min_k(int k);      // automatic mode: shortest reduction (elements) it takes
+int conv8_error(hipStream_t stream);
+long conv8_launches();
 
 // ------------------------------------------------------------------------------ wgrad.hip
 struct WgradParams {
