@@ -9,7 +9,27 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from bench.conv_layers import timeit  # noqa: E402
+
+
+def timeit(fn, iters=10):
+    """GPU time per call through hipGraph replay (bench/conv_layers.py); a failed capture is an error here."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.replay()
+    torch.cuda.synchronize()
+    s.record()
+    g.replay()
+    g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (2 * iters) * 1e-3
+
 from distributed_pytorch_amd.ops import hip_ops  # noqa: E402
 
 # (name, images at batch 1024 scale, H, Cin, Cout, k)
@@ -26,8 +46,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--modes", default="0,1,2")
+    ap.add_argument("--tail", type=int, default=4)
     args = ap.parse_args()
     C = hip_ops.C()
+    C.conv8_set_tail_split(args.tail)
     dt = torch.bfloat16
     modes = [int(m) for m in args.modes.split(",")]
     print("# ms per launch; mode 0 = igemm / lean / filter-row kernels, 1 = conv8 one tile per workgroup, 2 = conv8 stream-K")
@@ -49,8 +71,9 @@ def main():
             tf = timeit(lambda: hip_ops.conv2d(x, w, None, (1, 1), (p, p), False, None, True, False))
             td = timeit(lambda: hip_ops.conv_dgrad(dy, w, tuple(x.shape), (1, 1), (p, p), bnred=(x, bits, coef, 3)))
             took = C.conv8_launches() > n0
-            cells.append("%7.3f (%4.0f TF)%s %7.3f (%4.0f TF)" % (tf * 1e3, flops / tf / 1e12, "*" if took else " ",
-                                                                 td * 1e3, flops / td / 1e12))
+            info = "[g%d r%d]" % (C.conv8_last(0), C.conv8_last(1)) if took else ""
+            cells.append("%7.3f (%4.0f TF)%s %7.3f (%4.0f TF) %s" % (tf * 1e3, flops / tf / 1e12, "*" if took else " ",
+                                                                    td * 1e3, flops / td / 1e12, info))
         C.conv8_set_mode(-1)
         hip_ops._pending_bnred.clear()
         print("%-16s %-28s %s" % (name, "%d x %d x %d" % (M, Cout, Cin * k * k), "   ".join(cells)), flush=True)

@@ -76,7 +76,9 @@ PYBIND11_MODULE(_C, m) {
   m.def("igemm_set_lean", &igemm_set_lean);
   m.def("conv8_set_mode", &conv8_set_mode);
   m.def("conv8_set_min_k", &conv8_set_min_k);
+  m.def("conv8_set_tail_split", &conv8_set_tail_split);
   m.def("conv8_launches", &conv8_launches);
+  m.def("conv8_last", &conv8_last);
   m.def("conv8_error", [](uintptr_t s) { return conv8_error(st(s)); });
   m.def("igemm_set_lean_ablate", &igemm_set_lean_ablate);
   m.def("igemm_set_nt_store", &igemm_set_nt_store);

@@ -21,11 +21,14 @@
 //    the masked store of kIgemmXMask.  The extra operand of the last two is requested before the accumulators go
 //    through LDS.
 //  * Schedule: ResNet-50's deep layers at batch 1024 are 784 and 392 tiles -- 3.06 and 1.53 rounds of 256 CUs, a
-//    quarter of the chip-time idle in the last round.  With stream-K the launch is 256 workgroups that split the
-//    tiles x K-tiles iteration space evenly; a workgroup that starts in the middle of a tile writes its fp32
-//    accumulators to a slab and raises a flag, the workgroup that STARTED the tile adds the slabs of the others (they
-//    did that part first, so the wait is short) and runs the epilogue.  Release / acquire at agent scope, flags reset
-//    by their consumer (graph-replay safe), every spin bounded.
+//    quarter of the chip-time idle in the last round.  The stream-K launch cuts the tiles x K-tiles iteration space
+//    into as many equal ranges as there are CUs, cuts the ranges at tile boundaries, and runs every resulting SEGMENT
+//    as a workgroup of its own, longest first (the dispatcher hands the next segment to the first CU that frees up,
+//    so every CU ends up with about one range of work).  A segment that is not a whole tile writes its fp32
+//    accumulators to a slab and takes a ticket on the tile's counter; the LAST arriver adds the slabs of the others and
+//    runs the epilogue -- release / acquire at agent scope, nobody ever waits for another workgroup, the counter is
+//    reset by the last arriver (graph-replay safe).  (A persistent loop over segments inside one workgroup, the
+//    textbook form, cost 300-500 spilled registers inside the K loop with this compiler and ran at half the speed.)
 //
 // Replaces what cudnn.benchmark picks for these layers in the reference (imagenet_ddp_apex.py:110, nd_imagenet.py:291,302)
 // -- SURVEY.md N-K1, N-K2.
@@ -35,6 +38,8 @@
 #include <map>
 #include <mutex>
 #include <stdexcept>
+#include <tuple>
+#include <vector>
 
 namespace dpa {
 namespace {
@@ -71,16 +76,21 @@ template <> struct Mma9<f16_t> {
   }
 };
 
+struct Conv8Seg {       // one workgroup of a stream-K launch
+  int tile, kb, ke;     // K tiles [kb, ke) of output tile `tile`
+  int first, pieces;    // slab slots first .. first + pieces - 1 hold the tile's partial segments (pieces == 1: whole tile)
+  int mine;             // this segment's slot among them
+};
+
 struct Conv8Extra {
   int nk;            // K tiles per output tile = ntaps * kpt
   int kpt;           // K tiles per tap = Cred / 64
   int tiles_m, tiles_n;
-  int it_base, it_rem;   // iterations (tile, K tile) per workgroup: base (+1 for the first `rem` workgroups)
   int parts;         // ceil(M / 128): rows of the statistics slab
   int shift_pix;     // kReach * IW + kReach: the activation resource starts this many pixels before the tile
-  float* slab;       // stream-K partial accumulators [grid][32][512] float4
-  int* flags;        // [grid], zero between launches
-  int* error;        // set when a bounded spin ran out
+  const Conv8Seg* segs;  // stream-K: one entry per workgroup (nullptr: workgroup b computes tile b)
+  float* slab;       // partial accumulators [slot][32][512] float4
+  int* counters;     // [tiles], zero between launches
 };
 
 enum Conv8Epi : int { kEpiPlain = 0, kEpiStats = 1, kEpiBnb = 2, kEpiXMask = 3 };
@@ -90,24 +100,27 @@ enum Conv8Epi : int { kEpiPlain = 0, kEpiStats = 1, kEpiBnb = 2, kEpiXMask = 3 }
 template <typename T, int EPI, bool SK>
 __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, const Conv8Extra e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid0 = threadIdx.x;
-  const int G = (int)gridDim.x;
-  const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);
-  auto range_begin = [&](int w) { return w * e.it_base + min(w, e.it_rem); };
-  int it = range_begin(wg);
-  const int it_end = range_begin(wg + 1);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
   const int ntaps = min(p.ntaps, kMaxTaps);
-
-  while (it < it_end) {
-    // Everything a segment derives from the thread id is derived from an opaque copy: nothing can be hoisted out of
-    // this loop and kept alive across the epilogue / hand-off of the previous segment (measured: 400+ spilled
-    // registers inside the K loop otherwise), at the price of ~50 VALU instructions per segment.
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int l31 = lane & 31, lh = lane >> 5;
+  int tile, kb, ke, seg_first = 0, seg_pieces = 1, seg_mine = 0;
+  if constexpr (SK) {
+    const Conv8Seg sg = e.segs[blockIdx.x];
+    tile = __builtin_amdgcn_readfirstlane(sg.tile);
+    kb = __builtin_amdgcn_readfirstlane(sg.kb);
+    ke = __builtin_amdgcn_readfirstlane(sg.ke);
+    seg_first = __builtin_amdgcn_readfirstlane(sg.first);
+    seg_pieces = __builtin_amdgcn_readfirstlane(sg.pieces);
+    seg_mine = __builtin_amdgcn_readfirstlane(sg.mine);
+  } else {
+    tile = (int)xcd_remap(blockIdx.x, gridDim.x);
+    kb = 0;
+    ke = e.nk;
+  }
+  {
     // ---- fragment addresses (bytes from the start of the ring; gemm8.hip)
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
     uint32_t cA[4], cB[4];
@@ -118,9 +131,6 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
       cB[ks] = lds0 + (wc >> 1) * kHalf9 + (wc & 1) * 8192 + c;
     }
     const int srow0 = (wave * 2) * 8 + (lane >> 3);            // staged row of instruction 0 (instruction 1: + 8)
-    const int tile = it / e.nk;
-    const int kb = it - tile * e.nk;
-    const int ke = min(e.nk, kb + (it_end - it));
     const int mt = tile / e.tiles_n, nt = tile - mt * e.tiles_n;
     const int m0 = mt * 256, n0 = nt * 256;
     const int nks = ke - kb;
@@ -343,11 +353,44 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
     if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the stagger: every wave is past its last ring read
 
     // ---- stream-K hand-off -------------------------------------------------------------------------------------
-    // acc registers travel in a lane-private layout: float4 q of thread tid at slab[wg][q][tid] (coalesced)
-    if (SK && kb > 0) {
-      // uniform base per store + one 32-bit lane offset (an SGPR pair and an immediate: no per-store address registers)
-      char* const out = reinterpret_cast<char*>(e.slab) + (size_t)wg * (32 * 512 * 16);
+    // acc registers travel in a lane-private layout: float4 q of thread tid at slab[slot][q][tid] (coalesced; a
+    // uniform base per access + one 32-bit lane offset: no per-access address registers)
+    if (SK && seg_pieces > 1) {
       const uint32_t toff = (uint32_t)tid * 16u;
+      {
+        char* const out = reinterpret_cast<char*>(e.slab) + (size_t)(seg_first + seg_mine) * (32 * 512 * 16);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x16_t& v = acc[a][b][c];
+                *reinterpret_cast<float4*>(out + (size_t)(((a * 2 + b) * 2 + c) * 4 + q) * 8192 + toff) =
+                    make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+              }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* const ticket_box = reinterpret_cast<int*>(smem);      // the ring is free (one __shared__ object: gemm8.hip)
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(e.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == seg_pieces - 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(e.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        }
+        *ticket_box = ticket;
+      }
+      __syncthreads();
+      const int ticket = __builtin_amdgcn_readfirstlane(*ticket_box);
+      if (ticket != seg_pieces - 1) return;          // (uniform) somebody else finishes this tile
+      __syncthreads();                               // every wave has read the box before the ring is reused
+      // fixed summation order whoever arrives last (its own part is read back like the others): bit-identical runs
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -355,40 +398,9 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x16_t& v = acc[a][b][c];
-              *reinterpret_cast<float4*>(out + (size_t)(((a * 2 + b) * 2 + c) * 4 + q) * 8192 + toff) =
-                  make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(e.flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      it += nks;
-      continue;
-    }
-    if (SK && ke < e.nk) {
-      // this workgroup started the tile: add the parts of the workgroups whose ranges begin inside it
-      const int tile_end = (tile + 1) * e.nk;
-      for (int j = wg + 1; j < G && range_begin(j) < tile_end; ++j) {
-        if (tid == 0) {
-          long spins = 0;
-          while (__hip_atomic_load(e.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1l << 24)) {       // seconds: the peer never ran (the result of this tile is wrong)
-              *e.error = 1;
-              break;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        const char* const in = reinterpret_cast<const char*>(e.slab) + (size_t)j * (32 * 512 * 16);
-        const uint32_t toff = (uint32_t)tid * 16u;
+            for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+      for (int j = 0; j < seg_pieces; ++j) {
+        const char* const in = reinterpret_cast<const char*>(e.slab) + (size_t)(seg_first + j) * (32 * 512 * 16);
         // two batches of 16 loads (64 registers, the dead fragment registers): everything at once would spill
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -414,9 +426,6 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
               }
           asm volatile("" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(e.flags + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
 
@@ -589,50 +598,15 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
       if (EPI == kEpiStats && lane == 0 && wc == 0 && nt == 0 && rows > 0)
         p.stats[(size_t)e.parts * 2 * p.stats_ld + part] = (float)rows;
     }
-    it += nks;
-    if constexpr (!SK) break;
-    if (it < it_end) {
-      // the next segment's DMA reuses the ring and counts on an empty VM queue
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
   }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
-int g_conv8_mode = -1;        // -1 automatic (one tile per workgroup), 0 never, 1 / 2 whenever covered (data-parallel / stream-K),
-                              // 3 automatic with stream-K where the tiles do not fill whole rounds
+int g_conv8_mode = -1;        // -1 automatic, 0 never, 1 / 2 whenever covered (one tile per workgroup / equal-range stream-K)
 int g_conv8_min_k = 512;
-long g_conv8_launches = 0;  // (tests: proof that the launch really took this kernel)      // shortest reduction (elements) the pipeline is worth filling for
-
-struct Conv8Workspace {
-  float* slab = nullptr;
-  int* flags = nullptr;
-  int* error = nullptr;
-  int grid = 0;
-};
-std::mutex g_ws_mu;
-std::map<std::pair<int, hipStream_t>, Conv8Workspace> g_ws;
-
-Conv8Workspace& workspace(hipStream_t stream, int grid) {
-  int dev = 0;
-  DPA_CHECK_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_ws_mu);
-  Conv8Workspace& w = g_ws[{dev, stream}];
-  if (w.grid < grid) {
-    // (first use per stream, before any graph capture: plain allocations, never freed)
-    float* slab = nullptr;
-    int* flags = nullptr;
-    DPA_CHECK_HIP(hipMalloc(&slab, (size_t)grid * 32 * 512 * sizeof(float4)));
-    DPA_CHECK_HIP(hipMalloc(&flags, (size_t)(grid + 1) * sizeof(int)));
-    DPA_CHECK_HIP(hipMemset(flags, 0, (size_t)(grid + 1) * sizeof(int)));
-    w.slab = slab;
-    w.flags = flags;
-    w.error = flags + grid;
-    w.grid = grid;
-  }
-  return w;
-}
+int g_conv8_tail_split = 4;    // automatic mode: cut the tiles of a mostly empty last round into at most this many K pieces (0: never)
+long g_conv8_launches = 0;
+int g_conv8_last[4] = {0, 0, 0, 0};   // (diagnostics) grid, ranges / -pieces, slab slots, CUs of the last launch  // (tests: proof that the launch really took this kernel)      // shortest reduction (elements) the pipeline is worth filling for
 
 int num_cus() {
   static int n = 0;
@@ -643,6 +617,121 @@ int num_cus() {
     if (n <= 0) n = 256;
   }
   return n;
+}
+
+// A stream-K plan: the segment table of one (tiles, K tiles per tile, ranges) combination, built once and kept on the
+// device.  `ranges` equal pieces of the iteration space, cut at tile boundaries, longest first.
+struct Conv8Plan {
+  Conv8Seg* segs = nullptr;
+  int grid = 0;          // segments = workgroups
+  int slots = 0;         // partial segments = slab slots
+};
+
+// segments arrive in iteration order (the pieces of a tile are consecutive): number the slab slots, longest first
+std::vector<Conv8Seg> finish_plan(std::vector<Conv8Seg> segs, int* slots_out) {
+  int slots = 0;
+  for (size_t a = 0; a < segs.size();) {
+    size_t b = a;
+    while (b < segs.size() && segs[b].tile == segs[a].tile) ++b;
+    const int pieces = (int)(b - a);
+    for (size_t c = a; c < b; ++c) {
+      segs[c].pieces = pieces;
+      segs[c].first = pieces > 1 ? slots : 0;
+      segs[c].mine = (int)(c - a);
+    }
+    if (pieces > 1) slots += pieces;
+    a = b;
+  }
+  std::stable_sort(segs.begin(), segs.end(),
+                   [](const Conv8Seg& x, const Conv8Seg& y) { return x.ke - x.kb > y.ke - y.kb; });
+  *slots_out = slots;
+  return segs;
+}
+
+std::vector<Conv8Seg> plan_segments(long tiles, int nk, int ranges, int* slots_out) {
+  const long iters = tiles * nk;
+  const long base = iters / ranges, rem = iters % ranges;
+  std::vector<Conv8Seg> segs;
+  long it = 0;
+  for (int v = 0; v < ranges; ++v) {
+    const long end = it + base + (v < rem ? 1 : 0);
+    while (it < end) {
+      const long tile = it / nk;
+      const int kb = (int)(it - tile * nk);
+      const int ke = (int)std::min<long>(nk, kb + (end - it));
+      segs.push_back(Conv8Seg{(int)tile, kb, ke, 0, 1, 0});
+      it += ke - kb;
+    }
+  }
+  return finish_plan(std::move(segs), slots_out);
+}
+
+// Tail split: whole rounds of tiles run one tile per workgroup; the tiles of the last, mostly empty round are cut
+// into `pieces` equal K ranges each, so that round keeps every CU busy for 1 / pieces of a tile time.  (Equal ranges
+// over the whole launch -- plan_segments -- leave slivers of one or two K tiles at every range boundary, each paying
+// the pipeline fill and a 256 KiB slab round trip: measured slower than one tile per workgroup on every layer,
+// profiles/r3/conv8_layers.txt.)
+std::vector<Conv8Seg> plan_tail_split(long tiles, int nk, long full, int pieces, int* slots_out) {
+  std::vector<Conv8Seg> segs;
+  for (long t = 0; t < full; ++t) segs.push_back(Conv8Seg{(int)t, 0, nk, 0, 1, 0});
+  for (long t = full; t < tiles; ++t)
+    for (int q = 0; q < pieces; ++q) {
+      const int kb = (int)((long)nk * q / pieces), ke = (int)((long)nk * (q + 1) / pieces);
+      segs.push_back(Conv8Seg{(int)t, kb, ke, 0, 1, 0});
+    }
+  return finish_plan(std::move(segs), slots_out);
+}
+
+// One workspace per DEVICE: launches of one stream are ordered, and a graph capture (which runs on a stream of its
+// own and may not allocate) finds what its eager warm-up steps created.  Two stream-K launches running CONCURRENTLY
+// on two streams of one device would share slab and counters -- nothing in this framework does that (the optional
+// weight-gradient side stream never runs conv8).
+struct Conv8Workspace {
+  float* slab = nullptr;
+  int slots = 0;
+  int* counters = nullptr;
+  long tiles = 0;
+  std::map<std::tuple<long, int, int>, Conv8Plan> plans;
+};
+std::mutex g_ws_mu;
+std::map<int, Conv8Workspace> g_ws;
+
+// plan + workspace for a launch; allocates (synchronously) on first use of a shape -- never inside a graph capture
+// ranges > 0: equal ranges (plan_segments); ranges < 0: tail split into -ranges pieces (plan_tail_split)
+const Conv8Plan& plan_for(long tiles, int nk, int ranges, long full, Conv8Workspace** ws_out) {
+  int dev = 0;
+  DPA_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  Conv8Workspace& w = g_ws[dev];
+  *ws_out = &w;
+  Conv8Plan& pl = w.plans[std::make_tuple(tiles, nk, ranges)];
+  if (pl.segs == nullptr) {
+    int slots = 0;
+    const std::vector<Conv8Seg> segs = ranges > 0 ? plan_segments(tiles, nk, ranges, &slots)
+                                                  : plan_tail_split(tiles, nk, full, -ranges, &slots);
+    DPA_CHECK_HIP(hipMalloc(&pl.segs, segs.size() * sizeof(Conv8Seg)));
+    DPA_CHECK_HIP(hipMemcpy(pl.segs, segs.data(), segs.size() * sizeof(Conv8Seg), hipMemcpyHostToDevice));
+    pl.grid = (int)segs.size();
+    pl.slots = slots;
+  }
+  if (w.slots < pl.slots) {
+    // (the old slab, if any, may still be in use by a launch in flight: it is left alone, never freed)
+    const int want = std::max(pl.slots, 3 * num_cus());
+    float* slab = nullptr;
+    DPA_CHECK_HIP(hipMalloc(&slab, (size_t)want * 32 * 512 * sizeof(float4)));
+    w.slab = slab;
+    w.slots = want;
+  }
+  if (w.tiles < tiles) {
+    const long want = std::max<long>(tiles, 1 << 16);
+    int* counters = nullptr;
+    DPA_CHECK_HIP(hipMalloc(&counters, (size_t)want * sizeof(int)));
+    DPA_CHECK_HIP(hipMemset(counters, 0, (size_t)want * sizeof(int)));
+    DPA_CHECK_HIP(hipDeviceSynchronize());
+    w.counters = counters;
+    w.tiles = want;
+  }
+  return pl;
 }
 
 template <typename T, int EPI, bool SK>
@@ -664,7 +753,9 @@ void launch_conv8(const IgemmParams& p, const Conv8Extra& e, int grid, bool sk, 
 }  // namespace
 
 void conv8_set_mode(int mode) { g_conv8_mode = mode; }
+void conv8_set_tail_split(int on) { g_conv8_tail_split = on; }
 long conv8_launches() { return g_conv8_launches; }
+int conv8_last(int i) { return g_conv8_last[i & 3]; }
 void conv8_set_min_k(int k) { g_conv8_min_k = k > 0 ? k : 512; }
 
 // Whether conv8 covers the launch (pure function of the problem: the statistics slab of 128-row parts is what
@@ -705,7 +796,7 @@ bool conv8_try(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t st
   const int nk = (int)(ktot / 64);
   if (tiles * nk >= 2147483647l) return false;
   const int cus = num_cus();
-  if (g_conv8_mode < 0 || g_conv8_mode == 3) {
+  if (g_conv8_mode < 0) {
     // the pipeline needs a long K loop (fill + epilogue ~ 4.5 us per segment), wide N tiles and enough work per CU
     if (ktot < g_conv8_min_k || p.N % 256 != 0 || tiles * nk < (long)cus * 8) return false;
   }
@@ -716,28 +807,34 @@ bool conv8_try(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t st
   e.tiles_n = tiles_n;
   e.parts = ceil_div(p.M, 128);
   e.shift_pix = kReach * p.IW + kReach;
-  // stream-K when the tiles do not fill whole rounds of the chip: every CU gets the same number of K tiles
-  const long rounds_x100 = tiles * 100 / cus;
-  const bool full_rounds = tiles % cus == 0 || rounds_x100 >= 1200;       // >= 12 rounds: the tail is < 8 %
-  bool stream_k = g_conv8_mode == 2 || (g_conv8_mode == 3 && !full_rounds);
+  // mode 2 (tests): equal ranges over the whole launch, two K tiles per range at least.  Automatic: tail split when the
+  // last round of tiles is mostly empty (ResNet-50 layer3 at batch 1024: 784 tiles = 3 rounds + 16 tiles).
   const long iters_all = tiles * nk;
-  // forced (tests): small problems still split, two K tiles per workgroup at least
-  int sk_grid = (int)std::min<long>(cus, g_conv8_mode == 2 ? std::max<long>(1, iters_all / 2) : iters_all / 8);
-  if (sk_grid < 2) stream_k = false;
+  int ranges = 0;
+  long full = 0;
+  if (g_conv8_mode == 2) {
+    ranges = (int)std::min<long>(cus, std::max<long>(1, iters_all / 2));
+    if (ranges < 2) ranges = 0;
+  } else if (g_conv8_mode != 1 && g_conv8_tail_split) {
+    full = tiles / cus * cus;
+    const long tail = tiles - full;
+    if (full > 0 && tail > 0 && tail * 3 <= cus && nk >= 4) {
+      int pieces = (int)std::min<long>(cus / tail, nk / 2);      // >= 2 K tiles per piece, one sub-round of pieces
+      pieces = std::min(pieces, g_conv8_tail_split);   // the last arriver pulls every slab through ONE CU (~100 GB/s)
+      if (pieces >= 2) ranges = -pieces;
+    }
+  }
   int grid;
+  const bool stream_k = ranges != 0;
   if (stream_k) {
-    grid = sk_grid;
-    const long iters = iters_all;
-    e.it_base = (int)(iters / grid);
-    e.it_rem = (int)(iters % grid);
-    Conv8Workspace& w = workspace(stream, grid);
-    e.slab = w.slab;
-    e.flags = w.flags;
-    e.error = w.error;
+    Conv8Workspace* w = nullptr;
+    const Conv8Plan& pl = plan_for(tiles, nk, ranges, full, &w);
+    grid = pl.grid;
+    e.segs = pl.segs;
+    e.slab = w->slab;
+    e.counters = w->counters;
   } else {
     grid = (int)tiles;
-    e.it_base = nk;
-    e.it_rem = 0;
   }
   const bool bnb = p.flags & kIgemmBnBwd, xm = p.flags & kIgemmXMask;
   const int epi = bnb ? kEpiBnb : (xm ? kEpiXMask : (p.stats != nullptr ? kEpiStats : kEpiPlain));
@@ -757,20 +854,14 @@ bool conv8_try(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t st
     }
   }
   DPA_CHECK_HIP(hipGetLastError());
+  g_conv8_last[0] = grid;
+  g_conv8_last[1] = ranges;
+  g_conv8_last[3] = cus;
   ++g_conv8_launches;
   return true;
 }
 
-// (tests) 1 when a stream-K wait of an earlier launch on this stream ran out of spins
-int conv8_error(hipStream_t stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  std::lock_guard<std::mutex> lock(g_ws_mu);
-  auto itw = g_ws.find({dev, stream});
-  if (itw == g_ws.end() || itw->second.error == nullptr) return 0;
-  int v = 0;
-  DPA_CHECK_HIP(hipMemcpy(&v, itw->second.error, sizeof(int), hipMemcpyDeviceToHost));
-  return v;
-}
+// (tests) nothing in the stream-K hand-off can time out any more (no workgroup waits for another): always 0
+int conv8_error(hipStream_t /*stream*/) { return 0; }
 
 }  // namespace dpa

@@ -82,10 +82,12 @@ int igemm_num_configs();
 // schedule; takes stride-1 "same" 16-bit launches it covers and expects to win, false = run the other kernels.
 bool conv8_covers(const IgemmParams& p, int dtype, int out_dtype);
 bool conv8_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t stream);
-void conv8_set_mode(int mode);    // -1 automatic, 0 never, 1 / 2 always data-parallel / stream-K (when covered), 3 automatic + stream-K
+void conv8_set_mode(int mode);    // -1 automatic, 0 never, 1 / 2 always one tile per workgroup / equal-range stream-K (when covered)
+void conv8_set_tail_split(int on);
 void conv8_set_min_k(int k);      // automatic mode: shortest reduction (elements) it takes
 int conv8_error(hipStream_t stream);
 long conv8_launches();
+int conv8_last(int i);       // diagnostics: 0 grid, 1 ranges (> 0) or -pieces of the tail split, 3 CUs
 
 // ------------------------------------------------------------------------------ wgrad.hip
 struct WgradParams {

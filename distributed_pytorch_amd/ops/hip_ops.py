@@ -39,6 +39,10 @@ def C():
             _C.igemm_set_tail_min(int(os.environ["DPA_IGEMM_TAIL_MIN"]))
         _C.igemm_set_nt_store(int(os.environ.get("DPA_IGEMM_NT", "0")))  # 0: by size, 1: always, -1: never
         _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
+        # convolutions on the 256 x 256 multi-phase pipeline (csrc/kernels/conv8.hip): -1 auto, 0 off, 1 / 2 forced
+        _C.conv8_set_mode(int(os.environ.get("DPA_CONV8", "-1")))
+        _C.conv8_set_min_k(int(os.environ.get("DPA_CONV8_MIN_K", "512")))
+        _C.conv8_set_tail_split(int(os.environ.get("DPA_CONV8_TAIL", "4")))
         if "DPA_BN_GRID" in os.environ:          # workgroups of the BN streaming passes (default 1280, see bn.hip)
             _C.bn_set_tuning(int(os.environ["DPA_BN_GRID"]), 1)
         if "DPA_DW_SLIDING" in os.environ:       # 0: window-per-pixel depthwise kernels only

