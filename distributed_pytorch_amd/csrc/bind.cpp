@@ -74,6 +74,20 @@ PYBIND11_MODULE(_C, m) {
   m.def("igemm_set_row3", &igemm_set_row3);
   m.def("igemm_set_tail_min", &igemm_set_tail_min);
   m.def("igemm_set_lean", &igemm_set_lean);
+  m.attr("IGEMM_BN_FOLD") = (int)kIgemmBnFold;
+  m.def("bnfold_coeffs", [](uintptr_t raw, uintptr_t w, int ldw, uintptr_t dbeta_sum, uintptr_t mean, uintptr_t invstd,
+                            uintptr_t gamma, double count, int N, int C, uintptr_t dgamma_out, float beta_g,
+                            uintptr_t dbeta_out, float beta_b, uintptr_t coef, uintptr_t wt_scaled, uintptr_t ax, int dtype,
+                            uintptr_t s) {
+    bnfold_coeffs_launch(ptr<const float>(raw), ptr<const void>(w), ldw, ptr<const float>(dbeta_sum), ptr<const float>(mean),
+                         ptr<const float>(invstd), ptr<const float>(gamma), count, N, C, ptr<float>(dgamma_out), beta_g,
+                         ptr<float>(dbeta_out), beta_b, ptr<float>(coef), ptr<void>(wt_scaled), ptr<void>(ax), dtype, st(s));
+  });
+  m.def("bnfold_wgrad", [](uintptr_t raw, uintptr_t wg, uintptr_t coef, uintptr_t cs, uintptr_t out, int N, int C, float beta,
+                           uintptr_t s) {
+    bnfold_wgrad_launch(ptr<const float>(raw), ptr<const float>(wg), ptr<const float>(coef), ptr<const float>(cs),
+                        ptr<float>(out), N, C, beta, st(s));
+  });
   m.def("conv8_set_mode", &conv8_set_mode);
   m.def("conv8_set_min_k", &conv8_set_min_k);
   m.def("conv8_set_tail_split", &conv8_set_tail_split);

@@ -1,0 +1,106 @@
+// BatchNorm backward folded into the backward GEMMs of the 1x1 convolution that feeds it ("bn fold").
+//
+// For z = a W^T (1x1 convolution, W: [N][C]) followed by a training-mode BatchNorm, the BatchNorm backward
+//     dz = A * dy_m + B * z + K          (A, B, K per channel n; dy_m = dy through the ReLU mask)
+// is linear in dy_m and z, and z is linear in a, so the convolution's gradients need neither dz nor z:
+//     da = dy_m (diag(A) W) + a (W^T diag(B) W) + K^T W
+//     dW = diag(A) (dy_m^T a) + diag(B) W (a^T a) + K (x) colsum(a)
+// and the BatchNorm's own reduction  sum_m dy_m z = rowsum(W o (dy_m^T a))  falls out of the weight gradient.  The
+// activation-sized passes that disappear: the BatchNorm-backward apply pass (read dy, read z, write dz), the read of z
+// in the producer's fused reduction, and z itself no longer has to be kept for backward.  What is added are GEMMs on
+// the NARROW tensor a (a quarter of the channels in a bottleneck) and the two small kernels below.
+// (hip_ops._ConvFn / _BNFn "bn fold"; replaces cuDNN's batch-norm backward + convolution backward pair of
+// loss.backward() in the reference, nd_imagenet.py:302 -- SURVEY.md N-K2, N-K3, N-K5.)
+#include "../common.h"
+#include "kernels.h"
+#include <stdexcept>
+
+namespace dpa {
+namespace {
+
+// One workgroup per output channel n.  raw = dy_m^T a [N][C] (fp32), w = the 16-bit weights the forward pass used.
+template <typename T>
+__global__ __launch_bounds__(256) void bnfold_coeffs_kernel(
+    const float* __restrict__ raw, const T* __restrict__ w, int ldw, const float* __restrict__ dbeta_sum,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_count,
+    int N, int C, float* __restrict__ dgamma_out, float beta_g, float* __restrict__ dbeta_out, float beta_b,
+    float* __restrict__ coef, T* __restrict__ wt_scaled, T* __restrict__ ax) {
+  __shared__ float red[4];
+  __shared__ float abk[3];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float q = 0.f;
+  for (int c = tid; c < C; c += 256) q += to_float(w[(size_t)n * ldw + c]) * raw[(size_t)n * C + c];
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) {
+    const float Q = (red[0] + red[1]) + (red[2] + red[3]);          // sum_m dy_m z
+    const float db = dbeta_sum[n], is = invstd[n], mu = mean[n], g = gamma ? gamma[n] : 1.f;
+    const float dg = is * (Q - mu * db);                             // sum_m dy_m xhat
+    const float A = g * is;
+    const float B = -A * is * dg * inv_count;
+    const float K = -A * db * inv_count - B * mu;
+    dgamma_out[n] = (beta_g != 0.f ? beta_g * dgamma_out[n] : 0.f) + dg;
+    dbeta_out[n] = (beta_b != 0.f ? beta_b * dbeta_out[n] : 0.f) + db;
+    coef[n] = A;
+    coef[N + n] = B;
+    coef[2 * N + n] = K;
+    abk[0] = A; abk[1] = B; abk[2] = K;
+  }
+  __syncthreads();
+  const float A = abk[0], B = abk[1], K = abk[2];
+  for (int c = tid; c < C + 8; c += 256) {
+    if (c < C) {
+      const float wv = to_float(w[(size_t)n * ldw + c]);
+      wt_scaled[(size_t)c * N + n] = from_float<T>(A * wv);
+      ax[(size_t)c * N + n] = from_float<T>(B * wv);
+    } else {
+      ax[(size_t)c * N + n] = from_float<T>(c == C ? K : 0.f);
+    }
+  }
+}
+
+// dW[n][c] = beta * dW + A[n] * raw[n][c] + B[n] * wg[n][c] + K[n] * cs[c]     (wg = W (a^T a), cs = colsum(a))
+__global__ __launch_bounds__(256) void bnfold_wgrad_kernel(const float* __restrict__ raw, const float* __restrict__ wg,
+                                                           const float* __restrict__ coef, const float* __restrict__ cs,
+                                                           float* __restrict__ out, int N, int C, float beta) {
+  const long total = (long)N * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / C), c = (int)(i - (long)n * C);
+    float v = fmaf(coef[n], raw[i], fmaf(coef[N + n], wg[i], coef[2 * N + n] * cs[c]));
+    if (beta != 0.f) v += beta * out[i];
+    out[i] = v;
+  }
+}
+
+}  // namespace
+
+void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float* dbeta_sum, const float* mean,
+                          const float* invstd, const float* gamma, double count, int N, int C, float* dgamma_out,
+                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, void* ax, int dtype,
+                          hipStream_t s) {
+  if (N <= 0 || C <= 0) return;
+  const float inv = (float)(1.0 / count);
+  if (dtype == kBF16)
+    hipLaunchKernelGGL(bnfold_coeffs_kernel<bf16_t>, dim3(N), dim3(256), 0, s, raw, reinterpret_cast<const bf16_t*>(w), ldw,
+                       dbeta_sum, mean, invstd, gamma, inv, N, C, dgamma_out, beta_g, dbeta_out, beta_b, coef,
+                       reinterpret_cast<bf16_t*>(wt_scaled), reinterpret_cast<bf16_t*>(ax));
+  else if (dtype == kF16)
+    hipLaunchKernelGGL(bnfold_coeffs_kernel<f16_t>, dim3(N), dim3(256), 0, s, raw, reinterpret_cast<const f16_t*>(w), ldw,
+                       dbeta_sum, mean, invstd, gamma, inv, N, C, dgamma_out, beta_g, dbeta_out, beta_b, coef,
+                       reinterpret_cast<f16_t*>(wt_scaled), reinterpret_cast<f16_t*>(ax));
+  else
+    throw std::invalid_argument("bnfold: 16-bit compute types only");
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bnfold_wgrad_launch(const float* raw, const float* wg, const float* coef, const float* cs, float* out, int N, int C,
+                         float beta, hipStream_t s) {
+  if (N <= 0 || C <= 0) return;
+  const long total = (long)N * C;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(bnfold_wgrad_kernel, dim3(blocks), dim3(256), 0, s, raw, wg, coef, cs, out, N, C, beta);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace dpa

@@ -448,13 +448,23 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
       const char* xg = reinterpret_cast<const char*>(p.bn_x) + cb;
       const uint8_t* bits = reinterpret_cast<const uint8_t*>(p.bn_z) + (cb >> 4);
       const bool want_bits = EPI == kEpiBnb && (p.bn_relu & 3) == 3;
+      const bool fold = EPI == kEpiBnb && (p.flags & kIgemmBnFold);     // bn_x is not read (kernels.h)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const bool ok = col_ok && i * 8 + rsub < rows;
         const uint32_t lo = ok ? loff : 0u;              // (row 0 of an existing part always exists)
         const size_t ro = ok ? (size_t)i * rstep : 0;
-        px[i] = *reinterpret_cast<const uint4*>(xg + ro + lo);
         pbits[i] = want_bits ? bits[(ro >> 4) + (lo >> 4)] : 0xffu;
+      }
+      if (!fold) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool ok = col_ok && i * 8 + rsub < rows;
+          px[i] = *reinterpret_cast<const uint4*>(xg + (ok ? (size_t)i * rstep : 0) + (ok ? loff : 0u));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) px[i] = make_uint4(0u, 0u, 0u, 0u);
       }
     }
     float bv[2][4][4];
@@ -540,6 +550,13 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (!(xb.get(j) > 0.f)) v.set(j, 0.f);
+      }
+      if constexpr (EPI == kEpiBnb) {
+        if ((p.flags & kIgemmBnFold) && bn_mode == 3) {       // the gradient leaves already masked
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (!((pbits[i] >> j) & 1u)) v.set(j, 0.f);
+        }
       }
       char* dst = cg + (size_t)i * rstep + loff;
       if (nt_store) v.store_nt(dst);
@@ -770,6 +787,7 @@ bool conv8_covers(const IgemmParams& p, int dtype, int out_dtype) {
   if (p.M < 256 || p.N % 64 != 0 || p.Cred % 64 != 0 || p.lda % 8 || p.ldb % 8 || p.ldc % 8) return false;
   const bool bnb = p.flags & kIgemmBnBwd, xm = p.flags & kIgemmXMask;
   if (bnb && xm) return false;
+  if ((p.flags & kIgemmBnFold) && (!bnb || !(p.bn_relu == 0 || p.bn_relu == 3))) return false;
   if (bnb && (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || p.ldc != p.N ||
               (p.stats_ld != 0 && p.stats_ld != p.N) ||
               !(p.bn_relu == 0 || p.bn_relu == 2 || p.bn_relu == 6 || (p.bn_relu == 3 && p.bn_z != nullptr))))

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   };
   const int bn_mode = BNB ? (p.bn_relu & 3) : 0;   // 0 no ReLU, 2 mask recomputed from the BN input, 3 bit mask
   const bool bn_clip = BNB && (p.bn_relu & 4);     // ReLU6: the recomputed mask is 0 < y < 6
+  const bool bn_fold = BNB && (p.flags & kIgemmBnFold);   // masked store, sum dz_m only, bn_x not read (kernels.h)
   const char* const Rg = reinterpret_cast<const char*>(p.R) + cbase;
   const char* const Xg = reinterpret_cast<const char*>(p.bn_x) + cbase;
   const uint8_t* const rmask = RACC ? p.r_mask : nullptr;
@@ -321,9 +322,21 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
           q.rbits[i] = rmask != nullptr ? rmask[(cbase + off) >> 4] : 0xffu;
         }
       }
-      if constexpr (BNB) {
-        q.x[i] = *reinterpret_cast<const u32x4_t*>(Xg + off);
-        q.xbits[i] = xmask != nullptr ? xmask[(cbase + off) >> 4] : 0xffu;
+      if constexpr (BNB) q.xbits[i] = xmask != nullptr ? xmask[(cbase + off) >> 4] : 0xffu;
+    }
+    if constexpr (BNB) {
+      // (its own loop under ONE uniform branch: a per-load condition makes the compiler wait for every load in turn)
+      if (!bn_fold) {
+#pragma unroll
+        for (int i = 0; i < EH; ++i) {
+          const int it = half * EH + i;
+          const bool ok = er0 + it * RPE < rows;
+          const uint32_t off = ok ? coff0 + (uint32_t)it * cstep : (uint32_t)(ce * 16);
+          q.x[i] = *reinterpret_cast<const u32x4_t*>(Xg + off);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < EH; ++i) q.x[i] = u32x4_t{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -392,6 +405,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
         for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (((q.rbits[i] >> j) & 1u) ? r.get(j) : 0.f));
       }
       char* dst = Cg + (coff0 + (uint32_t)it * cstep);
+      if constexpr (BNB) {
+        if (bn_fold && MODE == 3) {       // the gradient leaves already masked (kIgemmBnFold)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (!((q.xbits[i] >> j) & 1u)) v.set(j, 0.f);
+        }
+      }
       if (ABL == 4) asm volatile("" ::"v"(v.raw.x), "v"(v.raw.y), "v"(v.raw.z), "v"(v.raw.w));
       else if (nt_store) v.store_nt(dst);
       else v.store(dst);
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
             if (!(yv > 0.f) || (bn_clip && !(yv < 6.f))) d = 0.f;
           }
           s1[j] += d;
-          s2[j] += d * ((xv - bmu[j]) * bis[j]);
+          s2[j] += d * ((xv - bmu[j]) * bis[j]);      // (fold: x = 0 here, the row is ignored by the consumer)
         }
       }
     }
@@ -592,6 +612,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;
   // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
   // from the full BN output (1) stays with the general kernel
+  if ((p.flags & kIgemmBnFold) && (!bnb || !(p.bn_relu == 0 || p.bn_relu == 3))) return false;
   if (bnb && (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || p.ldc != p.N ||
               !(p.bn_relu == 0 || p.bn_relu == 2 || p.bn_relu == 6 || (p.bn_relu == 3 && p.bn_z != nullptr))))
     return false;

@@ -116,6 +116,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   // barrier: loaded one dependent row at a time these launches ran at half the memory rate (profiles/r2_notes.md)
   uint4 px[E_IT], pz[E_IT];
   uint32_t pbits[E_IT];           // bn_relu == 3: bn_z is the BN's bit mask (one byte per 16-byte chunk)
+  const bool bn_fold = BNB && (p.flags & kIgemmBnFold);     // masked store, sum dz_m only, bn_x not read (kernels.h)
   auto bnb_request = [&](int first, int last) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < E_IT; ++i) {
@@ -123,7 +124,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       const uint32_t m = m0 + (tid + i * 256) / CE;
       const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0, no scatter
       const size_t goff = ok ? ((size_t)m * p.ldc + gofs + ncol) * sizeof(TOut) : 0;   // grouped: this group's slice
-      px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
+      if (bn_fold) px[i] = make_uint4(0u, 0u, 0u, 0u);
+      else px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
       if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);
       pbits[i] = p.bn_relu == 3 ? reinterpret_cast<const uint8_t*>(p.bn_z)[goff / 16] : 0u;
     }
@@ -236,6 +238,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
             v.set(j, v.get(j) + to_float(t));
           }
         }
+      }
+    }
+    if constexpr (BNB) {
+      if (bn_fold && p.bn_relu == 3) {       // the gradient leaves already masked (kIgemmBnFold)
+#pragma unroll
+        for (int j = 0; j < VECO; ++j)
+          if (!((pbits[i] >> j) & 1u)) v.set(j, 0.f);
       }
     }
     if constexpr (XM) {        // whole chunks only (the launch checks N % VECO == 0)
@@ -1269,6 +1278,8 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     if (p.N % veco != 0 || p.ldc != p.stats_ld)
       throw std::invalid_argument("igemm: fused BN-backward reduction needs dense rows of whole 16-byte chunks");
   }
+  if ((p.flags & kIgemmBnFold) && (!(p.flags & kIgemmBnBwd) || !(p.bn_relu == 0 || p.bn_relu == 3)))
+    throw std::invalid_argument("igemm: kIgemmBnFold needs the fused BN-backward reduction with no ReLU or a bit mask");
   if (p.flags & kIgemmXMask) {
     if (p.bn_x == nullptr || (p.flags & (kIgemmBnBwd | kIgemmScatter | kIgemmAxf)) || p.groups != 1 || p.ldc != p.N ||
         p.N % veco != 0 || dtype != out_dtype)

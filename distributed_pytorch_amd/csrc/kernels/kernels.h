@@ -14,11 +14,14 @@ namespace dpa {
 // kIgemmRStrided (lean GEMM only): R is compact [NB, OHF, OWF, ldc]; output pixel (y, x) adds R[y / OSY][x / OSX] when
 // y % OSY == 0 and x % OSX == 0 (powers of two) -- the data gradient of a strided 1x1 branch, never scattered into a
 // zero-filled full-size tensor.
+// kIgemmBnFold (with kIgemmBnBwd, bn_relu 0 or 3): the BatchNorm's producer is a 1x1 convolution whose backward folds the
+// BatchNorm backward into its own GEMMs (hip_ops._ConvFn, "bn fold"): the gradient is STORED through the ReLU mask, the
+// slab receives only sum dz_m (second row zeros) and bn_x is never read -- sum dz_m * xhat follows from the weight gradient.
 // kIgemmDense1: the caller guarantees ONE tap (0, 0, 0) -- a 1x1 convolution without padding or a Linear layer --
 // so every output pixel (oy, ox) reads input pixel (oy * SY, ox * SX): such launches may run the lean GEMM
 // (gemm_lean.hip: no tap bookkeeping, no padding masks).
 enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16,
-                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128, kIgemmXMask = 256 };
+                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128, kIgemmXMask = 256, kIgemmBnFold = 512 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -171,6 +174,18 @@ void bn_bwd_coeffs_launch(const float* dgamma, const float* dbeta, const float* 
 // dx = A*dy_m + B*x + K (coef rows 0..2), ReLU mask from y (relu 1) or from coef rows 3..4 and x (relu 2)
 void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx, void* dres, long M, int C,
                          int dtype, const float* coef, int relu, hipStream_t s);
+
+// ------------------------------------------------------------------------------ bnfold.hip
+// BatchNorm backward folded into the producing 1x1 convolution's backward GEMMs (see the file header).
+// raw = dy_m^T a [N][C] fp32, w = the 16-bit weights of the forward pass [N][ldw]; writes dgamma / dbeta (beta_*: accumulate
+// factors), coef [3][N] = (A, B, K), wt_scaled [C][N] = (A o W)^T and ax [C + 8][N] = ((B o W)^T ; K ; 0) in the compute dtype
+void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float* dbeta_sum, const float* mean,
+                          const float* invstd, const float* gamma, double count, int N, int C, float* dgamma_out,
+                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, void* ax, int dtype,
+                          hipStream_t s);
+// out[n][c] = beta * out + A[n] raw[n][c] + B[n] wg[n][c] + K[n] cs[c]
+void bnfold_wgrad_launch(const float* raw, const float* wg, const float* coef, const float* cs, float* out, int N, int C,
+                         float beta, hipStream_t s);
 
 // ------------------------------------------------------------------------------ pool.hip
 // idx (optional, uint8 per output element): tap code r*kw+q of the first arg-max, consumed by backward

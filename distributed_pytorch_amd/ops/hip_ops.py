@@ -95,6 +95,7 @@ def bump_generation() -> None:
     _premasked.clear()
     _pending_mask.clear()
     _pending_compact.clear()
+    _pending_fold.clear()
 
 
 class _WCache:
@@ -274,6 +275,8 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
     if bnred is not None:               # (bn input, bn output or None, coef[4][N], relu mode)
         flags |= C().IGEMM_BN_BWD
         bn_x, bn_z, bn_coef, bn_relu = bnred[0].data_ptr(), _p(bnred[1]), bnred[2].data_ptr(), bnred[3]
+        if len(bnred) > 4 and bnred[4]:     # "bn fold": masked store, sum dz_m only, the BN input is not read
+            flags |= C().IGEMM_BN_FOLD
     if xmask is not None:
         flags |= C().IGEMM_XMASK
         bn_x = xmask.data_ptr()
@@ -327,6 +330,149 @@ def _deliver(param, g):
     C().axpby(g.data_ptr(), _dt(g), s.view.data_ptr(), g.numel(), 1.0, s.beta(), _stream())
     s.delivered()
     return None
+
+
+# ------------------------------------------------------------------------------------------
+# BatchNorm backward folded into the producing 1x1 convolution ("bn fold", csrc/kernels/bnfold.hip)
+# ------------------------------------------------------------------------------------------
+_BN_FOLD = os.environ.get("DPA_BN_FOLD", "1") == "1"
+# expansion ratio (output / input channels) from which the fold is taken: the passes it removes stream the WIDE tensor,
+# the GEMMs it adds run on the narrow one
+_BN_FOLD_MIN_RATIO = float(os.environ.get("DPA_BN_FOLD_MIN_RATIO", "2"))
+_BN_FOLD_MIN_MB = float(os.environ.get("DPA_BN_FOLD_MIN_MB", "0"))
+# data_ptr of the NaN token a folded BatchNorm returned as "the gradient of its input" -> (token, dy (ReLU-masked), partial
+# slab with sum dy_m per part, BN coef [4][N], gamma, beta parameter, count, generation).  Consumed by _ConvFn.backward of
+# the 1x1 convolution that produced the BatchNorm's input.
+_pending_fold: Dict[int, tuple] = {}
+bn_fold_counts = {"folded": 0}
+
+
+def _bn_fold_eligible(x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip) -> bool:
+    if not (_BN_FOLD and want_stats and bias is None and not relu and not skip and needs_input_grad):
+        return False
+    if not (torch.is_grad_enabled() and x.is_cuda and x.requires_grad and weight.requires_grad):
+        return False
+    K, Cw, R, S = weight.shape
+    if (R, S) != (1, 1) or tuple(stride) != (1, 1) or tuple(padding) != (0, 0):
+        return False
+    if x.dtype not in (torch.bfloat16, torch.float16) or weight.dtype != torch.float32 or x.dim() != 4:
+        return False
+    Cx = x.shape[-1]
+    if Cx != Cw or Cx % 64 or K % 64 or K < _BN_FOLD_MIN_RATIO * Cx:
+        return False
+    if x.numel() // Cx * K * x.element_size() < _BN_FOLD_MIN_MB * 2 ** 20:
+        return False
+    return grad_sink.sink_of(weight) is not None
+
+
+def _wgrad_raw(dy2d_src, x_src, M, N, Cc, IH, IW) -> torch.Tensor:
+    """fp32 [N][Cc] = dy^T x over M pixel rows (dy: [M][N], x: [M][Cc], both dense) through the weight-gradient kernels."""
+    splits, pps = C().wgrad_choose_splits(M, N, Cc, _dt(dy2d_src))
+    slab = torch.empty((splits, N, Cc), dtype=torch.float32, device=dy2d_src.device)
+    taps = _tap_table(dy2d_src.device, ((0, 0, 0),))
+    st = _stream()
+    C().wgrad(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, N, Cc, 1, N, Cc, IH, IW,
+              1, 1, IH, IW, splits, pps, 1, _dt(dy2d_src), st, 1, 0, 0, 0, 0)
+    out = torch.empty((N, Cc), dtype=torch.float32, device=dy2d_src.device)
+    C().slab_reduce(slab.data_ptr(), splits, N * Cc, out.data_ptr(), 0, 0.0, st)
+    return out
+
+
+def _grad_into(param, fill):
+    """Gradient of `param` produced by `fill(view, beta)` (fp32, the parameter's memory layout): straight into the sink
+    view when there is one, else into a temporary that joins ``param.grad`` like autograd's accumulation would."""
+    s = grad_sink.sink_of(param)
+    if s is not None and _flat_same_layout(s.view, param):
+        fill(s.view, s.beta())
+        s.delivered()
+        return
+    g = torch.empty_like(param, dtype=torch.float32)
+    fill(g, 0.0)
+    g = g.to(param.dtype)
+    param.grad = g if param.grad is None else param.grad + g
+
+
+def _conv_bn_fold_backward(ctx, fent):
+    """Backward of (1x1 convolution -> training BatchNorm [+ residual + ReLU]) without the BatchNorm-backward apply pass:
+    see csrc/kernels/bnfold.hip for the algebra.  `fent` comes from _BNFn.backward, `ctx` is the convolution's."""
+    _, dy, part, coef, gamma, beta_p, count, _ = fent
+    a, weight, _ = ctx.saved_tensors
+    NB, IH, IW, Cx = a.shape
+    N = weight.shape[0]
+    M = NB * IH * IW
+    dev, dt, st = a.device, a.dtype, _stream()
+    bn_fold_counts["folded"] += 1
+    # ---- reductions over the pixels: raw = dy_m^T a, gram = a^T a, cs = colsum(a), dbeta = colsum(dy_m) (producer's slab)
+    raw = _wgrad_raw(dy, a, M, N, Cx, IH, IW)
+    gram = _wgrad_raw(a, a, M, Cx, Cx, IH, IW)
+    cs = _colsum(a.view(M, Cx))
+    dbeta_sum = torch.empty(N, dtype=torch.float32, device=dev)
+    scratch = torch.empty(N, dtype=torch.float32, device=dev)
+    C().bn_bwd_finalize(part.data_ptr(), part.shape[0], N, scratch.data_ptr(), dbeta_sum.data_ptr(), st)
+    # ---- BatchNorm coefficients (A, B, K), dgamma / dbeta, and the scaled weight operands
+    wlp = conv_weight(weight, dt, Cx)                                 # [N][Cx] as the forward pass used it
+    abk = torch.empty((3, N), dtype=torch.float32, device=dev)
+    wt_scaled = torch.empty((Cx, N), dtype=dt, device=dev)            # (A o W)^T: the data gradient's weight operand
+    ax = torch.empty((Cx + 8, N), dtype=dt, device=dev)               # (B o W)^T ; K ; 0
+    g32 = _f32(gamma.detach())
+    box = {}
+
+    def fill_gamma(view, beta):
+        box["g"] = (view, beta)
+
+    def fill_beta(view, beta):
+        box["b"] = (view, beta)
+        gv, gb = box["g"]
+        C().bnfold_coeffs(raw.data_ptr(), wlp.data_ptr(), Cx, dbeta_sum.data_ptr(), coef[0].data_ptr(),
+                          coef[1].data_ptr(), g32.data_ptr(), float(count), N, Cx, gv.data_ptr(), float(gb),
+                          view.data_ptr(), float(beta), abk.data_ptr(), wt_scaled.data_ptr(), ax.data_ptr(), _dt(a), st)
+
+    # (gamma's view is only noted; the kernel that fills both runs when beta's is known)
+    sg, sb = grad_sink.sink_of(gamma), grad_sink.sink_of(beta_p)
+    if sg is not None and sb is not None:
+        fill_gamma(sg.view, sg.beta())
+        fill_beta(sb.view, sb.beta())
+        sg.delivered()
+        sb.delivered()
+    else:
+        tg = torch.empty(N, dtype=torch.float32, device=dev)
+        tb = torch.empty(N, dtype=torch.float32, device=dev)
+        fill_gamma(tg, 0.0)
+        fill_beta(tb, 0.0)
+        for prm, t in ((gamma, tg), (beta_p, tb)):
+            r = _deliver(prm, t.to(prm.dtype))
+            if r is not None:
+                prm.grad = r if prm.grad is None else prm.grad + r
+    one = _tap_table(dev, ((0, 0, 0),))
+    dx = None
+    if ctx.needs_input_grad[0] and ctx.geom[3]:
+        # ---- G = W^T diag(B) W and bvec = K^T W in one small GEMM: out[c2][c1] = sum_n W[n][c2] ax[c1][n]
+        wt = conv_weight_t(weight, dt)                                # [Cx][N]
+        gk = torch.empty((Cx, Cx + 8), dtype=dt, device=dev)
+        _igemm(wt, ax, gk, None, None, one, Cx, Cx + 8, N, 1, N, N, Cx + 8, 1, Cx, 1, 1, 1, Cx, dtype=dt, out_dtype=dt)
+        bvec = gk[:, Cx].float().contiguous()
+        # ---- T = a G + bvec (narrow tensor), then da = dy_m (A o W) + T with the usual fused reduction for the BN before
+        T = torch.empty_like(a)
+        _igemm(a, gk, T, bvec, None, one, M, Cx, Cx, 1, Cx, Cx + 8, Cx, IH, IW, 1, 1, IH, IW, dtype=dt, out_dtype=dt)
+        src, ctx.bnsrc = ctx.bnsrc, None
+        bnred = None
+        if src is not None and src.uses == 1:
+            bnred = (src.x, a if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode,
+                     bool(src.fold))
+        dx = conv_dgrad(dy, weight, (NB, IH, IW, Cx), (1, 1), (0, 0), accum=T, bnred=bnred, wt_override=wt_scaled)
+    # ---- weight gradient: A o raw + B o (W gram) + K (x) cs, W gram in fp32 (the terms cancel)
+    if ctx.needs_input_grad[1]:
+        wg = torch.empty((N, Cx), dtype=torch.float32, device=dev)
+        w32 = weight.detach()
+        _igemm(w32, gram, wg, None, None, one, N, Cx, Cx, 1, Cx, Cx, Cx, 1, N, 1, 1, 1, N, dtype=torch.float32,
+               out_dtype=torch.float32)
+
+        def fill_w(view, beta):
+            C().bnfold_wgrad(raw.data_ptr(), wg.data_ptr(), abk.data_ptr(), cs.data_ptr(), view.data_ptr(), N, Cx,
+                             float(beta), st)
+
+        _grad_into(weight, fill_w)
+    return dx, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _ConvFn(torch.autograd.Function):
@@ -411,6 +557,11 @@ class _ConvFn(torch.autograd.Function):
             if amask is not None:
                 dalias = apply_bit_mask(dalias, amask)
             return dalias, None, None, None, None, None, None, None, None, None, None, None
+        fent = _pending_fold.pop(dy.data_ptr(), None)
+        if fent is not None:
+            if fent[-1] != _generation or tuple(fent[1].shape) != tuple(dy.shape):
+                raise RuntimeError("conv2d backward: stale BatchNorm-fold token")
+            return _conv_bn_fold_backward(ctx, fent)
         x, weight, y = ctx.saved_tensors
         axf = ctx.axf
         (sh, sw), (ph, pw), relu, needs_input_grad, has_bias = ctx.geom
@@ -452,7 +603,8 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and needs_input_grad:
             bnred = None
             if src is not None and src.uses == 1:                  # sole consumer of that BN's output
-                bnred = (src.x, x if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode)
+                bnred = (src.x, x if src.mode == 1 else (src.mask if src.mode == 3 else None), src.coef, src.mode,
+                         bool(src.fold))
             if ctx.compact and dalias is None:
                 # compact gradient: a plain GEMM over the output grid; autograd receives a NaN placeholder of the
                 # input's shape (zero strides, no memory) that only the alias' owner knows how to replace -- anything
@@ -584,10 +736,11 @@ bn_bwd_counts = {"fused": 0, "reduced": 0}      # how BatchNorm backward obtaine
 class _BnSrc:
     """Attached (as ``_dpa_bn``) to the output of a training-mode BatchNorm: what a consuming convolution needs
     to reduce that BN's backward sums inside its data-gradient epilogue."""
-    __slots__ = ("x", "coef", "mode", "uses", "mask")
+    __slots__ = ("x", "coef", "mode", "uses", "mask", "fold")
 
-    def __init__(self, x, coef, mode, mask=None):
+    def __init__(self, x, coef, mode, mask=None, fold=False):
         self.x, self.coef, self.mode, self.uses, self.mask = x, coef, mode, 0, mask
+        self.fold = fold        # the BN's backward is folded into its producing 1x1 convolution (see _conv_bn_fold_backward)
 
 
 def apply_bit_mask(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -598,13 +751,13 @@ def apply_bit_mask(t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 
 
 def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accum_mask=None, accum_stride=None,
-               xmask=None):
+               xmask=None, wt_override=None):
     NB, IH, IW, Cx = xshape
     K, Cw, R, S = weight.shape
     sh, sw = stride
     ph, pw = padding
     OH, OW = dy.shape[1], dy.shape[2]
-    wt = conv_weight_t(weight, dy.dtype)          # [Cw, R, S, K]
+    wt = conv_weight_t(weight, dy.dtype) if wt_override is None else wt_override          # [Cw, R, S, K]
     if Cx != Cw:
         raise ValueError("dgrad into a channel-padded input is not supported (stem has no input grad)")
     classes = _dgrad_classes(R, S, sh, sw, ph, pw)
@@ -647,7 +800,7 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
                SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
                bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask, rstride=rstride, xmask=xm)
         if slab is not None:
-            _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version)
+            _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version, len(bnred) > 4 and bool(bnred[4]))
         if xm is not None:
             _premasked[dx.data_ptr()] = (dx._version, _generation, xm.data_ptr())
     return dx
@@ -762,9 +915,14 @@ def conv2d(x, weight, bias, stride, padding, relu, w_lp, want_stats, needs_input
                                  weight.shape[2] * weight.shape[3] * Cx, _dt(x), _dt(x), 1)
         if not ok:
             x, axf = materialize(x), None
+    fold_ok = _bn_fold_eligible(x, weight, bias, stride, padding, relu, want_stats, needs_input_grad, skip)
+    if fold_ok and axf is not None:
+        x, axf = materialize(x), None       # the folded backward runs GEMMs on the normalised activation itself
     y, stats, alias = _ConvFn.apply(x, weight, bias, tuple(stride), tuple(padding), bool(relu), bool(want_stats),
                                     bool(needs_input_grad), bool(skip), getattr(x, "_dpa_bn", None), axf,
                                     _is_relu_out(x))
+    if fold_ok:
+        y._dpa_fold_ok = True
     if alias is not None:
         # its gradient returns to _ConvFn.backward (and nowhere else): a BatchNorm that takes it as the residual may
         # hand back the UNMASKED gradient plus its ReLU bit mask instead of writing a masked copy
@@ -1139,6 +1297,8 @@ class _BNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, nbt, momentum, eps, relu, stats,
                 group, defer=False, lazy_tok=None):
+        fold_ok = bool(getattr(x, "_dpa_fold_ok", False)) and x.is_contiguous()
+        ctx.fold = False
         x = x if x.is_contiguous() else x.contiguous()
         ctx.lazy_tok = lazy_tok
         Cc = x.shape[-1]
@@ -1237,8 +1397,10 @@ class _BNFn(torch.autograd.Function):
                             and residual.shape == x.shape and residual.dtype == x.dtype
                             and (getattr(residual, "_dpa_alias", False) or getattr(residual, "_dpa_bn_plain", False)))
         ctx.cfg = (relu_mode | clip | (act << 4), residual is not None, group, count)
+        # "bn fold": this BN's input comes from a 1x1 convolution whose backward can absorb the BN backward
+        ctx.fold = bool(fold_ok and relu_mode == 3 and not clip and not act and world == 1)
         # ReLU6 without a residual: the consumer recomputes 0 < scale * x + shift < 6 (mode 2 | 4)
-        _BNFn.last = None if (act or (clip and relu_mode != 2)) else _BnSrc(x, coef, relu_mode | clip, mask)
+        _BNFn.last = None if (act or (clip and relu_mode != 2)) else _BnSrc(x, coef, relu_mode | clip, mask, ctx.fold)
         return y
 
     @staticmethod
@@ -1259,6 +1421,14 @@ class _BNFn(torch.autograd.Function):
         st = _stream()
         dev = x.device
         fused = _pending_bnred.pop(dy.data_ptr(), None)
+        if fused is not None and len(fused) > 3 and fused[3]:
+            # the producer stored dy THROUGH the ReLU mask and reduced sum dy_m only ("bn fold")
+            if ctx.fold and fused[1] == x.data_ptr() and fused[2] == dy._version and ctx.needs_input_grad[0]:
+                token = torch.full((1,), float("nan"), dtype=dy.dtype, device=dev).expand(x.shape)
+                _pending_fold[token.data_ptr()] = (token, dy, fused[0], coef, weight, ctx.bias_ref, count, _generation)
+                dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+                return token, None, None, dres, None, None, None, None, None, None, None, None, None, None
+            fused = None            # (a masked gradient is still a valid input of the ordinary path: masking is idempotent)
         if fused is not None and fused[1] == x.data_ptr() and fused[2] == dy._version:
             part = fused[0]         # the producing data-gradient kernel already reduced (sum dy_m, sum dy_m*xhat)
             bn_bwd_counts["fused"] += 1

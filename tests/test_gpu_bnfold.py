@@ -1,0 +1,109 @@
+"""BatchNorm backward folded into the producing 1x1 convolution (csrc/kernels/bnfold.hip, hip_ops._conv_bn_fold_backward):
+a stack of bottleneck blocks trained one step with the fold on and off, and against a plain PyTorch fp32 reference of
+the same network fed the same rounded parameters."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from distributed_pytorch_amd import amp, models  # noqa: E402
+from distributed_pytorch_amd.models.resnet import Bottleneck  # noqa: E402
+from distributed_pytorch_amd.ops import functional as F  # noqa: E402
+from distributed_pytorch_amd.ops import hip_ops  # noqa: E402
+from distributed_pytorch_amd.optim import FusedSGD  # noqa: E402
+from _gpu_util import assert_close  # noqa: E402
+
+DEV = "cuda"
+
+
+class Stack(torch.nn.Module):
+    def __init__(self, planes=64, blocks=3):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([Bottleneck(planes * 4, planes) for _ in range(blocks)])
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return x
+
+
+def _run(fold, planes, shape, seed=0):
+    torch.manual_seed(seed)
+    net = Stack(planes).to(DEV).train()
+    for m in net.modules():           # non-trivial BN parameters
+        if hasattr(m, "running_mean") and m.weight is not None and m.weight.dim() == 1:
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    opt = FusedSGD(net.parameters(), lr=0.0, momentum=0.0)
+    net, opt = amp.initialize(net, opt, opt_level="O2", dtype="bf16")
+    N, H, W = shape
+    x = (torch.randn(N, H, W, planes * 4, device=DEV).relu() + 0.1).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(N, H, W, planes * 4, device=DEV).to(torch.bfloat16)
+    old = hip_ops._BN_FOLD
+    hip_ops._BN_FOLD = fold
+    hip_ops.bn_fold_counts["folded"] = 0
+    try:
+        opt.zero_grad()
+        y = net(x)
+        y.backward(gy)
+    finally:
+        hip_ops._BN_FOLD = old
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
+    return net, x, gy, y.detach().float(), x.grad.detach().float(), grads, hip_ops.bn_fold_counts["folded"]
+
+
+@pytest.mark.parametrize("planes,shape", [(64, (4, 14, 14)), (128, (3, 9, 11))])
+def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, shape):
+    net, x, gy, y1, dx1, g1, folded = _run(True, planes, shape)
+    _, _, _, y0, dx0, g0, none = _run(False, planes, shape)
+    assert folded == 2 and none == 0          # blocks 0 and 1: their bn3 receives a fused, pre-masked gradient
+    assert torch.equal(y1, y0)
+    # fp32 reference with the SAME (bf16-rounded) weights and input
+    def ref_block(blk, t):
+        def cbr(t, conv, bn, relu, res=None):
+            w = conv.weight.detach().to(torch.bfloat16).float()
+            z = TF.conv2d(t, w, None, conv.stride, conv.padding)
+            o = TF.batch_norm(z, None, None, bn.weight.detach().float(), bn.bias.detach().float(), True, 0.0, bn.eps)
+            if res is not None:
+                o = o + res
+            return TF.relu(o) if relu else o
+        o = cbr(t, blk.conv1, blk.bn1, True)
+        o = cbr(o, blk.conv2, blk.bn2, True)
+        return cbr(o, blk.conv3, blk.bn3, True, t)
+    params = {n: p for n, p in net.named_parameters()}
+    leaves = {n: p.detach().float().requires_grad_(True) for n, p in params.items()}
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    # rebuild with leaves: simplest is to substitute through functional calls
+    t = xr
+    for i, blk in enumerate(net.blocks):
+        def cbr(t, cname, bname, conv, bn, relu, res=None):
+            w = leaves[cname + ".weight"].to(torch.bfloat16).float() + (leaves[cname + ".weight"] - leaves[cname + ".weight"].detach())
+            z = TF.conv2d(t, w, None, conv.stride, conv.padding)
+            o = TF.batch_norm(z, None, None, leaves[bname + ".weight"], leaves[bname + ".bias"], True, 0.0, bn.eps)
+            if res is not None:
+                o = o + res
+            return TF.relu(o) if relu else o
+        pre = "blocks.%d." % i
+        o = cbr(t, pre + "conv1", pre + "bn1", blk.conv1, blk.bn1, True)
+        o = cbr(o, pre + "conv2", pre + "bn2", blk.conv2, blk.bn2, True)
+        t = cbr(o, pre + "conv3", pre + "bn3", blk.conv3, blk.bn3, True, t)
+    t.backward(gy.float().permute(0, 3, 1, 2))
+    # The network runs bf16 activations through three blocks (ReLU masks flip, roundings accumulate): per-element bounds
+    # against an fp32 reference are meaningless here.  Tensor-level: the fold differs from the ordinary backward by
+    # roundings only (it never rounds dz to bf16), and it is no further from the fp32 reference than the ordinary one.
+    def rel(a, b):
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+    assert torch.isfinite(dx1).all()
+    assert rel(dx1, dx0) < 2e-2
+    e1, e0 = rel(dx1.permute(0, 3, 1, 2), xr.grad), rel(dx0.permute(0, 3, 1, 2), xr.grad)
+    assert e1 <= 1.25 * e0 + 1e-3, ("input gradient", e1, e0)
+    for n in g1:
+        assert torch.isfinite(g1[n]).all(), n
+        assert rel(g1[n], g0[n]) < 2e-2, (n, rel(g1[n], g0[n]))
+        ref = leaves[n].grad.reshape(g1[n].shape)
+        e1, e0 = rel(g1[n], ref), rel(g0[n], ref)
+        assert e1 <= 1.25 * e0 + 1e-3, (n, e1, e0)
