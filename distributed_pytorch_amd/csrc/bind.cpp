@@ -29,8 +29,10 @@ PYBIND11_MODULE(_C, m) {
            int Cred, int ntaps, int lda, int ldb, int ldc, int IH, int IW, int SY, int SX, int OH, int OW, int OHF,
            int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream,
            uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu, int groups, long a_gstride, long b_gstride,
-           long c_gstride, int stats_ld, uintptr_t r_mask, uintptr_t a_scale, uintptr_t a_shift) {
+           long c_gstride, int stats_ld, uintptr_t r_mask, uintptr_t a_scale, uintptr_t a_shift, uintptr_t a2, int lda2,
+           int cred2) {
           IgemmParams p;
+          p.A2 = ptr<const void>(a2); p.lda2 = lda2; p.Cred2 = cred2;
           p.r_mask = ptr<const uint8_t>(r_mask);
           p.a_scale = ptr<const float>(a_scale);
           p.a_shift = ptr<const float>(a_shift);
@@ -63,7 +65,7 @@ PYBIND11_MODULE(_C, m) {
         py::arg("dtype"), py::arg("out_dtype"), py::arg("stream"), py::arg("bn_x") = 0, py::arg("bn_z") = 0,
         py::arg("bn_coef") = 0, py::arg("bn_relu") = 0, py::arg("groups") = 1, py::arg("a_gstride") = 0,
         py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0, py::arg("r_mask") = 0,
-        py::arg("a_scale") = 0, py::arg("a_shift") = 0);
+        py::arg("a_scale") = 0, py::arg("a_shift") = 0, py::arg("a2") = 0, py::arg("lda2") = 0, py::arg("cred2") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
   m.attr("IGEMM_AXF") = (int)kIgemmAxf;
   m.attr("IGEMM_DENSE1") = (int)kIgemmDense1;
@@ -77,11 +79,11 @@ PYBIND11_MODULE(_C, m) {
   m.attr("IGEMM_BN_FOLD") = (int)kIgemmBnFold;
   m.def("bnfold_coeffs", [](uintptr_t raw, uintptr_t w, int ldw, uintptr_t dbeta_sum, uintptr_t mean, uintptr_t invstd,
                             uintptr_t gamma, double count, int N, int C, uintptr_t dgamma_out, float beta_g,
-                            uintptr_t dbeta_out, float beta_b, uintptr_t coef, uintptr_t wt_scaled, uintptr_t ax, int dtype,
+                            uintptr_t dbeta_out, float beta_b, uintptr_t coef, uintptr_t wt_scaled, int ldwt, uintptr_t ax, int dtype,
                             uintptr_t s) {
     bnfold_coeffs_launch(ptr<const float>(raw), ptr<const void>(w), ldw, ptr<const float>(dbeta_sum), ptr<const float>(mean),
                          ptr<const float>(invstd), ptr<const float>(gamma), count, N, C, ptr<float>(dgamma_out), beta_g,
-                         ptr<float>(dbeta_out), beta_b, ptr<float>(coef), ptr<void>(wt_scaled), ptr<void>(ax), dtype, st(s));
+                         ptr<float>(dbeta_out), beta_b, ptr<float>(coef), ptr<void>(wt_scaled), ldwt, ptr<void>(ax), dtype, st(s));
   });
   m.def("bnfold_wgrad", [](uintptr_t raw, uintptr_t wg, uintptr_t coef, uintptr_t cs, uintptr_t out, int N, int C, float beta,
                            uintptr_t s) {
@@ -115,8 +117,10 @@ PYBIND11_MODULE(_C, m) {
   m.def("wgrad",
         [](uintptr_t dY, uintptr_t X, uintptr_t slab, uintptr_t taps, int M, int N, int Cred, int ntaps, int ldy,
            int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int taps_zero, int dtype,
-           uintptr_t stream, int groups, long y_gstride, long x_gstride, uintptr_t x_scale, uintptr_t x_shift) {
+           uintptr_t stream, int groups, long y_gstride, long x_gstride, uintptr_t x_scale, uintptr_t x_shift,
+           uintptr_t dY2, int N2, int ldy2) {
           WgradParams p;
+          p.dY2 = ptr<const void>(dY2); p.N2 = N2; p.ldy2 = ldy2;
           p.x_scale = ptr<const float>(x_scale);
           p.x_shift = ptr<const float>(x_shift);
           p.groups = groups; p.y_gstride = y_gstride; p.x_gstride = x_gstride; p.slab_rows = groups * N;
@@ -136,7 +140,7 @@ PYBIND11_MODULE(_C, m) {
         py::arg("ntaps"), py::arg("ldy"), py::arg("ldx"), py::arg("IH"), py::arg("IW"), py::arg("SY"), py::arg("SX"),
         py::arg("OH"), py::arg("OW"), py::arg("splits"), py::arg("pps"), py::arg("taps_zero"), py::arg("dtype"),
         py::arg("stream"), py::arg("groups") = 1, py::arg("y_gstride") = 0, py::arg("x_gstride") = 0,
-        py::arg("x_scale") = 0, py::arg("x_shift") = 0);
+        py::arg("x_scale") = 0, py::arg("x_shift") = 0, py::arg("dY2") = 0, py::arg("N2") = 0, py::arg("ldy2") = 0);
   m.def("slab_reduce", [](uintptr_t slab, int splits, long n, uintptr_t out, int out_dtype, float beta, uintptr_t s) {
     slab_reduce_launch(ptr<const float>(slab), splits, n, ptr<void>(out), out_dtype, beta, st(s));
   });

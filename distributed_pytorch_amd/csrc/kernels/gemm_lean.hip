@@ -57,8 +57,10 @@ int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 fo
 
 // BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
+// CAT: the reduction runs over two gathered operands back to back (IgemmParams::A2): when the K tiles of the first are
+// used up the staging base and the per-row offsets switch to the second, nothing else in the loop changes.
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false, bool AXF = false>
+          bool BIAS = false, bool AXF = false, bool CAT = false>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BM = 128;
@@ -110,6 +112,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 #pragma unroll
   for (int i = 0; i < B_IT; ++i)
     boff[i] = ((uint32_t)(r0 + i * RPI) * (uint32_t)p.ldb + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
+  uint32_t aoff2[CAT ? A_IT : 1];
+  const char* Ag2 = nullptr;
+  int cat_left = CAT ? p.Cred / BK : 0;          // K tiles of the first operand still to request
+  if constexpr (CAT) {
+    Ag2 = reinterpret_cast<const char*>(p.A2) + (size_t)pix0 * p.lda2 * sizeof(T);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      uint32_t m = (uint32_t)(m0 + r0 + i * RPI);
+      m = m < (uint32_t)p.M ? m : (uint32_t)p.M - 1u;
+      aoff2[i] = ((pixel(m) - pix0) * (uint32_t)p.lda2 + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
+    }
+  }
 
   // ---- LDS addresses (loop invariant) ---------------------------------------------------------------------
   unsigned char* const wr_a = smem + r0 * LDR + ch * 16;                       // + i * RPI * LDR
@@ -156,6 +170,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
     __syncthreads();
   }
   auto load_tile = [&](int set) __attribute__((always_inline)) {
+    if constexpr (CAT) {
+      if (cat_left-- == 0) {                     // (uniform, once per kernel) on to the second operand
+        Ag = Ag2;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) aoff[i] = aoff2[i];
+      }
+    }
     if constexpr (AXF) axf_q[set] = (axf_kt++) * CPR + ch;
     if ((ABL == 3 || ABL >= 5) && Ag != reinterpret_cast<const char*>(p.A) + (size_t)pix0 * p.lda * sizeof(T)) {
       Ag += BKB;      // (keeps the first-tile test of store_tile exact)
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   auto loop_sync = [&]() __attribute__((always_inline)) {
     if (ABL != 6) __syncthreads();      // ablation 6: how much of the pure read + MFMA loop is barrier skew
   };
-  const int nk = p.Cred / BK;
+  const int nk = p.Cred / BK + (CAT ? p.Cred2 / BK : 0);
   int kt = 0;
   if constexpr (PF == 1) {
     load_tile(0);
@@ -507,18 +528,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 }
 
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false, bool AXF = false>
+          bool BIAS = false, bool AXF = false, bool CAT = false>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
   constexpr int epi_bytes = 128 * (BN * 2 + 16);
   constexpr int red_bytes = 9 * BN * 4;
   constexpr int max_lds = (2 * stage_bytes > epi_bytes ? 2 * stage_bytes : epi_bytes) + (AXF ? 8 * 2048 : 0);
-  int lds = (p.Cred * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
+  int lds = ((p.Cred + p.Cred2) * 2 > BKB ? 2 : 1) * stage_bytes;     // one K tile: no second staging buffer
   if (AXF) lds = 2 * stage_bytes + 8 * p.Cred;            // (scale, shift) table behind both stages
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF, CAT>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -535,6 +556,11 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   const bool stats = p.stats != nullptr && !bnb, racc = p.R != nullptr;
   if (p.flags & kIgemmAxf) {           // forward with BN + ReLU applied on load: always wants the next BN's statistics
     launch_lean<T, BN, BKB, MINB, PF, true, false, false, false, 0, false, true>(p, stream);
+    return;
+  }
+  if (p.A2 != nullptr) {               // two operands back to back + bias ("bn fold" data gradient), plain or with the reduction
+    if (bnb) launch_lean<T, BN, BKB, MINB, PF, false, false, true, false, 0, true, false, true>(p, stream);
+    else launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true, false, true>(p, stream);
     return;
   }
   if (p.bias != nullptr) {             // Linear forward (gemm_lean_try admits a bias only on the plain variant)
@@ -579,9 +605,9 @@ void launch_lean_tiles(const IgemmParams& p, bool strided, hipStream_t stream) {
   const long tiles = (long)ceil_div(p.M, 128) * (p.N / (wide ? 128 : 64));
   // 128-byte K tiles (half the barriers) for long reductions and launches that barely fill the chip, as in
   // igemm.hip's choose_cfg(); 64-byte K tiles (more workgroups per CU) otherwise
-  bool k128 = p.Cred % 64 == 0 && ((long)p.Cred * 2 >= 4096 || tiles <= 512);
+  bool k128 = p.Cred % 64 == 0 && p.Cred2 % 64 == 0 && ((long)(p.Cred + p.Cred2) * 2 >= 4096 || tiles <= 512);
   if (g_lean_mode == 1) k128 = false;
-  if (g_lean_mode == 2) k128 = p.Cred % 64 == 0;
+  if (g_lean_mode == 2) k128 = p.Cred % 64 == 0 && p.Cred2 % 64 == 0;
   // PF = 2 (two K tiles in flight in registers) measured the same as PF = 1 on every ResNet-50 layer
   // (profiles/r2/lean_gemm_prefetch_depth.txt): the K loop is not what these launches wait for
   if (wide) {
@@ -608,7 +634,11 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   const bool bnb = p.flags & kIgemmBnBwd;
   // bias (+ ReLU): Linear layers, plain epilogue only
   if ((p.flags & kIgemmRelu) && p.bias == nullptr) return false;
-  if (p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;
+  const bool cat = p.A2 != nullptr;
+  if (cat && (p.bias == nullptr || p.R != nullptr || (p.stats != nullptr && !bnb) || p.Cred2 <= 0 || p.Cred2 % 32 ||
+              p.lda2 % 8 || (p.flags & (kIgemmAxf | kIgemmRStrided))))
+    return false;
+  if (!cat && p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;
   if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;
   // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
   // from the full BN output (1) stays with the general kernel
@@ -621,7 +651,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   // every output pixel reads pixel (oy * SY, ox * SX): must exist
   if ((oh - 1) * p.SY >= p.IH || (ow - 1) * p.SX >= p.IW) return false;
   const bool strided = !(p.SY == 1 && p.SX == 1 && (long)p.IH * p.IW == ohow && p.IW == ow);
-  if (strided && (p.R != nullptr || bnb || p.bias != nullptr)) return false;
+  if (strided && (p.R != nullptr || bnb || p.bias != nullptr || cat)) return false;
   if ((p.flags & kIgemmAxf) && (p.stats == nullptr || p.R != nullptr || bnb || p.bias != nullptr || strided ||
                                 p.a_scale == nullptr || p.a_shift == nullptr || p.Cred > 2048))
     return false;

@@ -1288,13 +1288,16 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     p.bn_z = nullptr;
   }
   t_xmask_done = false;
-  if (g_force_cfg < 0 && conv8_try(p, dtype, out_dtype, stream)) return;
-  if (!(p.flags & kIgemmXMask) && (p.flags & kIgemmDense1) && g_force_cfg < 0 && gemm_lean_try(p, dtype, out_dtype, stream)) {
+  if (g_force_cfg < 0 && p.A2 == nullptr && conv8_try(p, dtype, out_dtype, stream)) return;
+  if (!(p.flags & kIgemmXMask) && (p.flags & kIgemmDense1) && (g_force_cfg < 0 || p.A2 != nullptr) &&
+      gemm_lean_try(p, dtype, out_dtype, stream)) {
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
   if (p.flags & kIgemmRStrided)
     throw std::invalid_argument("igemm: a compact strided accumulate is only implemented by the lean GEMM");
+  if (p.A2 != nullptr)
+    throw std::invalid_argument("igemm: a second gathered operand is only implemented by the lean GEMM (dense 1x1, 16-bit)");
   if (dtype == kF32 && out_dtype == kF32) dispatch_tiles<float, float>(p, stream);
   else if (dtype == kBF16 && out_dtype == kBF16) dispatch_tiles<bf16_t, bf16_t>(p, stream);
   else if (dtype == kBF16 && out_dtype == kF32) dispatch_tiles<bf16_t, float>(p, stream);

@@ -42,6 +42,11 @@ struct IgemmParams {
   int bn_relu;
   const float* a_scale = nullptr;   // kIgemmAxf: [Cred] each
   const float* a_shift = nullptr;
+  // second gathered operand (lean GEMM only, dense 1x1): the reduction continues over Cred2 channels of A2 (rows of lda2
+  // elements, same pixels), against columns Cred .. Cred + Cred2 - 1 of B -- C = [A | A2] [B1 | B2]^T in one launch
+  // (the "bn fold" data gradient: dy_m (A o W) + a (W^T diag(B) W))
+  const void* A2 = nullptr;
+  int lda2 = 0, Cred2 = 0;
   // grouped convolution: grid.y = group; a group's slice starts g * stride ELEMENTS into each operand (groups
   // <= 1: dense).  N, Cred are per group; bias / statistics are indexed by the global channel g * c_gstride + n,
   // stats_ld is the slab's row width (all groups; 0 = N).
@@ -109,6 +114,10 @@ struct WgradParams {
   // X is the raw input z of a BatchNorm + ReLU: the kernel stages relu(x_scale[c] * z + x_shift[c]) (16-bit, dense)
   const float* x_scale = nullptr;
   const float* x_shift = nullptr;
+  // second gradient operand (dense 1x1 problems only): output rows N .. N + N2 - 1 are dY2^T X with dY2 [M][ldy2] -- the
+  // Gram matrix X^T X of the "bn fold" (dY2 = X) rides the launch that computes dY^T X, X is staged once for both
+  const void* dY2 = nullptr;
+  int N2 = 0, ldy2 = 0;
   FastDiv div_ohow, div_ow;
 };
 void wgrad_launch(const WgradParams& p, int dtype, hipStream_t stream);
@@ -178,10 +187,10 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
 // ------------------------------------------------------------------------------ bnfold.hip
 // BatchNorm backward folded into the producing 1x1 convolution's backward GEMMs (see the file header).
 // raw = dy_m^T a [N][C] fp32, w = the 16-bit weights of the forward pass [N][ldw]; writes dgamma / dbeta (beta_*: accumulate
-// factors), coef [3][N] = (A, B, K), wt_scaled [C][N] = (A o W)^T and ax [C + 8][N] = ((B o W)^T ; K ; 0) in the compute dtype
+// factors), coef [3][N] = (A, B, K), wt_scaled [C][ldwt] = (A o W)^T and ax [C + 8][N] = ((B o W)^T ; K ; 0) in the compute dtype
 void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float* dbeta_sum, const float* mean,
                           const float* invstd, const float* gamma, double count, int N, int C, float* dgamma_out,
-                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, void* ax, int dtype,
+                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, int ldwt, void* ax, int dtype,
                           hipStream_t s);
 // out[n][c] = beta * out + A[n] raw[n][c] + B[n] wg[n][c] + K[n] cs[c]
 void bnfold_wgrad_launch(const float* raw, const float* wg, const float* coef, const float* cs, float* out, int N, int C,

@@ -58,22 +58,28 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
 
-  const uint32_t tiles_i = (p.N + BI - 1) / BI, tiles_j = (p.Ktot + BJ - 1) / BJ;
+  const uint32_t tiles_i1 = (p.N + BI - 1) / BI;
+  const uint32_t tiles_i = tiles_i1 + (p.N2 + BI - 1) / BI, tiles_j = (p.Ktot + BJ - 1) / BJ;
   const uint32_t tiles = tiles_i * tiles_j;
   const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t split = lid / tiles, tile = lid - split * tiles;
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
-  const int i0 = ti * BI, j0 = tj * BJ;
+  // output-row tiles past the first operand's belong to the second gradient operand (WgradParams::dY2): uniform per
+  // workgroup, so it is a choice of base pointer, row stride and row count made once
+  const bool second = (uint32_t)ti >= tiles_i1;
+  const int i0 = (second ? ti - (int)tiles_i1 : ti) * BI, j0 = tj * BJ;
+  const int Nloc = second ? p.N2 : p.N, ldyl = second ? p.ldy2 : p.ldy;
+  const int row_base = second ? p.N : 0;            // first slab row of this operand
 
   const int m_begin = split * p.pix_per_split;
   const int m_end = min(p.M, m_begin + p.pix_per_split);
 
-  const char* __restrict__ Yg = reinterpret_cast<const char*>(p.dY) + (size_t)blockIdx.y * p.y_gstride * sizeof(T);
+  const char* __restrict__ Yg = reinterpret_cast<const char*>(second ? p.dY2 : p.dY) + (size_t)blockIdx.y * p.y_gstride * sizeof(T);
   const char* __restrict__ Xg = reinterpret_cast<const char*>(p.X) + (size_t)blockIdx.y * p.x_gstride * sizeof(T);
 
   // fixed per-thread columns
   const int cp = tid % CPP;                   // dY chunk column
-  const bool pok = i0 + cp * VEC < p.N;       // N is a multiple of VEC
+  const bool pok = i0 + cp * VEC < Nloc;      // N is a multiple of VEC
   const int cq = tid % CPQ;                   // im2col chunk column
   const int kcol = j0 + cq * VEC;
   const bool qok = kcol < p.Ktot;
@@ -99,17 +105,17 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   uint32_t poff[P_IT], qoff[Q_IT], pmask[PF][P_IT], qmask[PF][Q_IT];
   // LIN: 32-bit byte offsets relative to the first pixel of THIS workgroup's split (64-bit bases), so only one split's
   // rows have to span less than 4 GiB (host checked) -- the tensors themselves may be any size
-  const char* __restrict__ Yl = Yg + (LIN ? (size_t)m_begin * p.ldy * sizeof(T) : (size_t)0);
+  const char* __restrict__ Yl = Yg + (LIN ? (size_t)m_begin * ldyl * sizeof(T) : (size_t)0);
   const char* __restrict__ Xl = Xg + (LIN ? (size_t)m_begin * p.ldx * sizeof(T) : (size_t)0);
   if (LIN) {
 #pragma unroll
     for (int i = 0; i < P_IT; ++i)
-      poff[i] = (uint32_t)(((uint32_t)((tid + i * NT) / CPP) * (uint32_t)p.ldy + i0 + cp * VEC) * sizeof(T));
+      poff[i] = (uint32_t)(((uint32_t)((tid + i * NT) / CPP) * (uint32_t)ldyl + i0 + cp * VEC) * sizeof(T));
 #pragma unroll
     for (int i = 0; i < Q_IT; ++i)
       qoff[i] = (uint32_t)(((uint32_t)((tid + i * NT) / CPQ) * (uint32_t)p.ldx + kcol) * sizeof(T));
   }
-  const uint32_t pstep = (uint32_t)(BKP * p.ldy * (int)sizeof(T)), qstep = (uint32_t)(BKP * p.ldx * (int)sizeof(T));
+  const uint32_t pstep = (uint32_t)(BKP * ldyl * (int)sizeof(T)), qstep = (uint32_t)(BKP * p.ldx * (int)sizeof(T));
   // generic gather: incremental pixel coordinates of the rows this thread stages
   const int OWg = (int)p.div_ow.d, OHg = (int)(p.div_ohow.d / p.div_ow.d);
   const int step_n = BKP / (OHg * OWg), step_r = BKP - step_n * OHg * OWg;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
       const int m = m_base + row;
       const bool ok = pok && m < m_end;
       pmask[S][i] = ok ? 0xffffffffu : 0u;
-      rp[S][i] = *reinterpret_cast<const uint4*>(Yg + (ok ? ((size_t)m * p.ldy + i0 + cp * VEC) * sizeof(T) : (size_t)0));
+      rp[S][i] = *reinterpret_cast<const uint4*>(Yg + (ok ? ((size_t)m * ldyl + i0 + cp * VEC) * sizeof(T) : (size_t)0));
     }
     if (m_base != q_next) {                     // (re)seed the incremental coordinates
 #pragma unroll
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   }
 
   // acc[a][b][r]: i = wi*WTI + a*32 + (r&3) + 8*(r>>2) + 4*lh ; j = wj*WTJ + b*32 + l31
-  float* __restrict__ out = p.slab + ((size_t)split * p.slab_rows + (size_t)blockIdx.y * p.N) * p.Ktot;
+  float* __restrict__ out = p.slab + ((size_t)split * p.slab_rows + (size_t)blockIdx.y * p.N + row_base) * p.Ktot;
 #pragma unroll
   for (int a = 0; a < MI; ++a)
 #pragma unroll
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi * WTI + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (i < p.N && j < p.Ktot) out[(size_t)i * p.Ktot + j] = acc[a][b][r];
+        if (i < Nloc && j < p.Ktot) out[(size_t)i * p.Ktot + j] = acc[a][b][r];
       }
     }
 }
@@ -366,11 +372,12 @@ template <typename T, int BI, int BJ, int KB, int WI, int WJ, int PF, bool XF>
 void launch_cfg_x(const WgradParams& p, hipStream_t stream) {
   constexpr int BKP = KB / (int)sizeof(T);
   constexpr int lds = 2 * BKP * ((BI + BJ) * (int)sizeof(T) + 128);
-  const long blocks = (long)ceil_div(p.N, BI) * ceil_div(p.Ktot, BJ) * p.splits;
+  const long blocks = (long)(ceil_div(p.N, BI) + ceil_div(p.N2, BI)) * ceil_div(p.Ktot, BJ) * p.splits;
   const int es = (int)sizeof(T);
   const bool lin = p.ntaps == 1 && p.SY == 1 && p.SX == 1 && p.taps_zero &&
                    (long)p.div_ohow.d == (long)p.IH * p.IW && (int)p.div_ow.d == p.IW &&
                    ((double)p.pix_per_split + 2.0 * BKP) * p.ldy * es < 4294967296.0 &&
+                   ((double)p.pix_per_split + 2.0 * BKP) * p.ldy2 * es < 4294967296.0 &&
                    ((double)p.pix_per_split + 2.0 * BKP) * p.ldx * es < 4294967296.0;
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
@@ -473,10 +480,13 @@ void wgrad_launch(const WgradParams& p_in, int dtype, hipStream_t stream) {
   WgradParams p = p_in;
   const int vec = dtype == kF32 ? 4 : 8;
   if (p.M <= 0 || p.N <= 0 || p.Ktot <= 0) return;
+  if (p.dY2 == nullptr) p.N2 = p.ldy2 = 0;
+  if (p.N2 > 0 && (p.groups > 1 || !(p.ntaps == 1 && p.taps_zero) || p.N2 % vec != 0 || p.ldy2 % vec != 0))
+    throw std::invalid_argument("wgrad: a second gradient operand needs a dense 1x1 problem and 16-byte aligned rows");
   if (p.groups <= 1) {
     p.groups = 1;
     p.y_gstride = p.x_gstride = 0;
-    p.slab_rows = p.N;
+    p.slab_rows = p.N + p.N2;
   } else {
     if (p.y_gstride % vec || p.x_gstride % vec || p.groups > 65535 || p.slab_rows != p.groups * p.N)
       throw std::invalid_argument("wgrad: bad group layout");

@@ -41,15 +41,16 @@ def _run(fold, planes, shape, seed=0):
     N, H, W = shape
     x = (torch.randn(N, H, W, planes * 4, device=DEV).relu() + 0.1).to(torch.bfloat16).requires_grad_(True)
     gy = torch.randn(N, H, W, planes * 4, device=DEV).to(torch.bfloat16)
-    old = hip_ops._BN_FOLD
+    old, old_mb = hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB
     hip_ops._BN_FOLD = fold
+    hip_ops._BN_FOLD_MIN_MB = 0.0           # (the default leaves tensors this small to the ordinary backward)
     hip_ops.bn_fold_counts["folded"] = 0
     try:
         opt.zero_grad()
         y = net(x)
         y.backward(gy)
     finally:
-        hip_ops._BN_FOLD = old
+        hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB = old, old_mb
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
     return net, x, gy, y.detach().float(), x.grad.detach().float(), grads, hip_ops.bn_fold_counts["folded"]

@@ -514,7 +514,7 @@ def test_dgrad_epilogue_bn_backward_partials(mode, k, with_accum):
     hip_ops._pending_bnred.clear()
     dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum,
                             bnred=(bn_x, z if mode in (1, 3) else None, coef, mode))
-    slab, xptr, _ = hip_ops._pending_bnred.pop(dx.data_ptr())
+    slab, xptr = hip_ops._pending_bnred.pop(dx.data_ptr())[:2]
     assert xptr == bn_x.data_ptr()
     ref_dx = hip_ops.conv_dgrad(dy, w, (N, H, H, Cin), (1, 1), (p, p), accum=accum)
     # the gradient itself is untouched (3x3: the reference launch takes the filter-row kernel, whose fp32
