@@ -30,9 +30,10 @@ PYBIND11_MODULE(_C, m) {
            int OWF, int OSY, int OSX, int OY0, int OX0, int flags, int dtype, int out_dtype, uintptr_t stream,
            uintptr_t bn_x, uintptr_t bn_z, uintptr_t bn_coef, int bn_relu, int groups, long a_gstride, long b_gstride,
            long c_gstride, int stats_ld, uintptr_t r_mask, uintptr_t a_scale, uintptr_t a_shift, uintptr_t a2, int lda2,
-           int cred2) {
+           int cred2, uintptr_t b2, int ldb2) {
           IgemmParams p;
           p.A2 = ptr<const void>(a2); p.lda2 = lda2; p.Cred2 = cred2;
+          p.B2 = ptr<const void>(b2); p.ldb2 = ldb2;
           p.r_mask = ptr<const uint8_t>(r_mask);
           p.a_scale = ptr<const float>(a_scale);
           p.a_shift = ptr<const float>(a_shift);
@@ -65,7 +66,8 @@ PYBIND11_MODULE(_C, m) {
         py::arg("dtype"), py::arg("out_dtype"), py::arg("stream"), py::arg("bn_x") = 0, py::arg("bn_z") = 0,
         py::arg("bn_coef") = 0, py::arg("bn_relu") = 0, py::arg("groups") = 1, py::arg("a_gstride") = 0,
         py::arg("b_gstride") = 0, py::arg("c_gstride") = 0, py::arg("stats_ld") = 0, py::arg("r_mask") = 0,
-        py::arg("a_scale") = 0, py::arg("a_shift") = 0, py::arg("a2") = 0, py::arg("lda2") = 0, py::arg("cred2") = 0);
+        py::arg("a_scale") = 0, py::arg("a_shift") = 0, py::arg("a2") = 0, py::arg("lda2") = 0, py::arg("cred2") = 0, py::arg("b2") = 0,
+        py::arg("ldb2") = 0);
   m.attr("IGEMM_BN_BWD") = (int)kIgemmBnBwd;
   m.attr("IGEMM_AXF") = (int)kIgemmAxf;
   m.attr("IGEMM_DENSE1") = (int)kIgemmDense1;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void bnfold_coeffs_kernel(
     const float* __restrict__ raw, const T* __restrict__ w, int ldw, const float* __restrict__ dbeta_sum,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_count,
     int N, int C, float* __restrict__ dgamma_out, float beta_g, float* __restrict__ dbeta_out, float beta_b,
-    float* __restrict__ coef, T* __restrict__ wt_scaled, int ldwt, T* __restrict__ ax) {
+    float* __restrict__ coef, T* __restrict__ wt_scaled, int ldwt, T* __restrict__ bw) {
   __shared__ float red[4];
   __shared__ float abk[3];
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void bnfold_coeffs_kernel(
     if (c < C) {
       const float wv = to_float(w[(size_t)n * ldw + c]);
       wt_scaled[(size_t)c * ldwt + n] = from_float<T>(A * wv);
-      ax[(size_t)c * N + n] = from_float<T>(B * wv);
+      bw[(size_t)n * (C + 8) + c] = from_float<T>(B * wv);
     } else {
-      ax[(size_t)c * N + n] = from_float<T>(c == C ? K : 0.f);
+      bw[(size_t)n * (C + 8) + c] = from_float<T>(c == C ? K : 0.f);
     }
   }
 }
@@ -77,18 +77,18 @@ __global__ __launch_bounds__(256) void bnfold_wgrad_kernel(const float* __restri
 
 void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float* dbeta_sum, const float* mean,
                           const float* invstd, const float* gamma, double count, int N, int C, float* dgamma_out,
-                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, int ldwt, void* ax, int dtype,
+                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, int ldwt, void* bw, int dtype,
                           hipStream_t s) {
   if (N <= 0 || C <= 0) return;
   const float inv = (float)(1.0 / count);
   if (dtype == kBF16)
     hipLaunchKernelGGL(bnfold_coeffs_kernel<bf16_t>, dim3(N), dim3(256), 0, s, raw, reinterpret_cast<const bf16_t*>(w), ldw,
                        dbeta_sum, mean, invstd, gamma, inv, N, C, dgamma_out, beta_g, dbeta_out, beta_b, coef,
-                       reinterpret_cast<bf16_t*>(wt_scaled), ldwt, reinterpret_cast<bf16_t*>(ax));
+                       reinterpret_cast<bf16_t*>(wt_scaled), ldwt, reinterpret_cast<bf16_t*>(bw));
   else if (dtype == kF16)
     hipLaunchKernelGGL(bnfold_coeffs_kernel<f16_t>, dim3(N), dim3(256), 0, s, raw, reinterpret_cast<const f16_t*>(w), ldw,
                        dbeta_sum, mean, invstd, gamma, inv, N, C, dgamma_out, beta_g, dbeta_out, beta_b, coef,
-                       reinterpret_cast<f16_t*>(wt_scaled), ldwt, reinterpret_cast<f16_t*>(ax));
+                       reinterpret_cast<f16_t*>(wt_scaled), ldwt, reinterpret_cast<f16_t*>(bw));
   else
     throw std::invalid_argument("bnfold: 16-bit compute types only");
   DPA_CHECK_HIP(hipGetLastError());

@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 #pragma unroll
   for (int i = 0; i < B_IT; ++i)
     boff[i] = ((uint32_t)(r0 + i * RPI) * (uint32_t)p.ldb + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
-  uint32_t aoff2[CAT ? A_IT : 1];
+  uint32_t aoff2[CAT ? A_IT : 1], boff2[CAT ? B_IT : 1];
   const char* Ag2 = nullptr;
+  const char* Bg2 = nullptr;
   int cat_left = CAT ? p.Cred / BK : 0;          // K tiles of the first operand still to request
   if constexpr (CAT) {
     Ag2 = reinterpret_cast<const char*>(p.A2) + (size_t)pix0 * p.lda2 * sizeof(T);
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       uint32_t m = (uint32_t)(m0 + r0 + i * RPI);
       m = m < (uint32_t)p.M ? m : (uint32_t)p.M - 1u;
       aoff2[i] = ((pixel(m) - pix0) * (uint32_t)p.lda2 + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
+    }
+    if (p.B2 != nullptr) {
+      Bg2 = reinterpret_cast<const char*>(p.B2) + (size_t)n0 * p.ldb2 * sizeof(T);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i)
+        boff2[i] = ((uint32_t)(r0 + i * RPI) * (uint32_t)p.ldb2 + (uint32_t)(ch * VEC)) * (uint32_t)sizeof(T);
     }
   }
 
@@ -175,6 +182,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
         Ag = Ag2;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) aoff[i] = aoff2[i];
+        if (Bg2 != nullptr) {
+          Bg = Bg2;
+#pragma unroll
+          for (int i = 0; i < B_IT; ++i) boff[i] = boff2[i];
+        }
       }
     }
     if constexpr (AXF) axf_q[set] = (axf_kt++) * CPR + ch;
@@ -636,7 +648,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if ((p.flags & kIgemmRelu) && p.bias == nullptr) return false;
   const bool cat = p.A2 != nullptr;
   if (cat && (p.bias == nullptr || p.R != nullptr || (p.stats != nullptr && !bnb) || p.Cred2 <= 0 || p.Cred2 % 32 ||
-              p.lda2 % 8 || (p.flags & (kIgemmAxf | kIgemmRStrided))))
+              p.lda2 % 8 || (p.B2 != nullptr && p.ldb2 % 8) || (p.flags & (kIgemmAxf | kIgemmRStrided))))
     return false;
   if (!cat && p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;
   if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;

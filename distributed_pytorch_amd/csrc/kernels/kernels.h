@@ -47,6 +47,8 @@ struct IgemmParams {
   // (the "bn fold" data gradient: dy_m (A o W) + a (W^T diag(B) W))
   const void* A2 = nullptr;
   int lda2 = 0, Cred2 = 0;
+  const void* B2 = nullptr;         // optional: the second range's weights live in their own matrix [N][ldb2] (else: in B)
+  int ldb2 = 0;
   // grouped convolution: grid.y = group; a group's slice starts g * stride ELEMENTS into each operand (groups
   // <= 1: dense).  N, Cred are per group; bias / statistics are indexed by the global channel g * c_gstride + n,
   // stats_ld is the slab's row width (all groups; 0 = N).
@@ -187,10 +189,10 @@ void bn_bwd_apply_launch(const void* dy, const void* x, const void* y, void* dx,
 // ------------------------------------------------------------------------------ bnfold.hip
 // BatchNorm backward folded into the producing 1x1 convolution's backward GEMMs (see the file header).
 // raw = dy_m^T a [N][C] fp32, w = the 16-bit weights of the forward pass [N][ldw]; writes dgamma / dbeta (beta_*: accumulate
-// factors), coef [3][N] = (A, B, K), wt_scaled [C][ldwt] = (A o W)^T and ax [C + 8][N] = ((B o W)^T ; K ; 0) in the compute dtype
+// factors), coef [3][N] = (A, B, K), wt_scaled [C][ldwt] = (A o W)^T and bw [N][C + 8] = (B o W | K | 0) in the compute dtype
 void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float* dbeta_sum, const float* mean,
                           const float* invstd, const float* gamma, double count, int N, int C, float* dgamma_out,
-                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, int ldwt, void* ax, int dtype,
+                          float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, int ldwt, void* bw, int dtype,
                           hipStream_t s);
 // out[n][c] = beta * out + A[n] raw[n][c] + B[n] wg[n][c] + K[n] cs[c]
 void bnfold_wgrad_launch(const float* raw, const float* wg, const float* coef, const float* cs, float* out, int N, int C,

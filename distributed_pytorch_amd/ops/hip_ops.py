@@ -257,8 +257,8 @@ def _conv_out(i, k, s, p):
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
            scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False,
            accum_mask=None, axf=None, rstride=None, xmask=None, cat=None):
-    """``cat``: (A2, lda2, Cred2) -- the reduction continues over a second gathered operand against the next Cred2
-    columns of B (lean GEMM, dense 1x1; needs a bias).
+    """``cat``: (A2, lda2, Cred2[, B2, ldb2]) -- the reduction continues over a second gathered operand against the next
+    Cred2 columns of B, or against B2 (lean GEMM, dense 1x1; needs a bias).
     ``xmask``: a ReLU output with the layout of the result; result elements where it is <= 0 are stored as 0.
     ``groups``: (count, a_gstride, b_gstride, c_gstride, stats_ld) -- one launch, grid.y = group.
     ``rstride``: (OHc, OWc, sy, sx) -- ``accum`` is the COMPACT gradient [NB, OHc, OWc, N] of a stride-s 1x1 branch
@@ -292,7 +292,8 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
     C().igemm(A.data_ptr(), B.data_ptr(), Cout_t.data_ptr(), _p(accum), _p(bias), _p(stats), taps.data_ptr(), M, N, Cred,
               ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW, OHF, OWF, OSY, OSX, OY0, OX0, flags,
               _dt(dtype), _dt(out_dtype), _stream(), bn_x, bn_z, bn_coef, bn_relu, *gargs, _p(accum_mask),
-              a_scale, a_shift, *((cat[0].data_ptr(), cat[1], cat[2]) if cat is not None else (0, 0, 0)))
+              a_scale, a_shift, *((cat[0].data_ptr(), cat[1], cat[2]) if cat is not None else (0, 0, 0)),
+              *((cat[3].data_ptr(), cat[4]) if cat is not None and len(cat) > 3 else (0, 0)))
 
 
 def _stats_slab(nparts: int, C_: int, device) -> torch.Tensor:
@@ -369,19 +370,22 @@ def _bn_fold_eligible(x, weight, bias, stride, padding, relu, want_stats, needs_
     return grad_sink.sink_of(weight) is not None
 
 
-def _wgrad_raw(dy2d_src, x_src, M, N, Cc, IH, IW, gram: bool = False) -> torch.Tensor:
-    """fp32 [N][Cc] = dy^T x over M pixel rows (dy: [M][N], x: [M][Cc], both dense) through the weight-gradient kernels.
-    ``gram``: the same launch also produces x^T x; the result is [N + Cc][Cc] (x is staged once for both)."""
+def _wgrad_raw(dy2d_src, x_src, M, N, Cc, IH, IW, gram: bool = False, out_dtype=torch.float32, ldy=None, ldx=None) -> torch.Tensor:
+    """[N][Cc] = dy^T x over M pixel rows (dy: [M][ldy >= N], x: [M][ldx >= Cc]) through the weight-gradient kernels (fp32
+    accumulation, result in ``out_dtype``).  ``gram``: the same launch also produces x^T x; the result is [N + Cc][Cc]
+    (x is staged once for both)."""
+    ldy = N if ldy is None else ldy
+    ldx = Cc if ldx is None else ldx
     splits, pps = C().wgrad_choose_splits(M, N, Cc, _dt(dy2d_src))
     rows = N + (Cc if gram else 0)
     slab = torch.empty((splits, rows, Cc), dtype=torch.float32, device=dy2d_src.device)
     taps = _tap_table(dy2d_src.device, ((0, 0, 0),))
     st = _stream()
-    C().wgrad(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, N, Cc, 1, N, Cc, IH, IW,
+    C().wgrad(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, N, Cc, 1, ldy, ldx, IH, IW,
               1, 1, IH, IW, splits, pps, 1, _dt(dy2d_src), st, 1, 0, 0, 0, 0,
-              x_src.data_ptr() if gram else 0, Cc if gram else 0, Cc if gram else 0)
-    out = torch.empty((rows, Cc), dtype=torch.float32, device=dy2d_src.device)
-    C().slab_reduce(slab.data_ptr(), splits, rows * Cc, out.data_ptr(), 0, 0.0, st)
+              x_src.data_ptr() if gram else 0, Cc if gram else 0, ldx if gram else 0)
+    out = torch.empty((rows, Cc), dtype=out_dtype, device=dy2d_src.device)
+    C().slab_reduce(slab.data_ptr(), splits, rows * Cc, out.data_ptr(), _dt(out_dtype), 0.0, st)
     return out
 
 
@@ -415,13 +419,13 @@ def _conv_bn_fold_backward(ctx, fent):
     cs = _colsum(a.view(M, Cx))
     dbeta_sum = torch.empty(N, dtype=torch.float32, device=dev)
     scratch = torch.empty(N, dtype=torch.float32, device=dev)
-    C().bn_bwd_finalize(part.data_ptr(), part.shape[0], N, scratch.data_ptr(), dbeta_sum.data_ptr(), st)
+    partf = _fold(part, N)              # (thousands of 128-row parts: folded by many workgroups first)
+    C().bn_bwd_finalize(partf.data_ptr(), partf.shape[0], N, scratch.data_ptr(), dbeta_sum.data_ptr(), st)
     # ---- BatchNorm coefficients (A, B, K), dgamma / dbeta, and the scaled weight operands
     wlp = conv_weight(weight, dt, Cx)                                 # [N][Cx] as the forward pass used it
     abk = torch.empty((3, N), dtype=torch.float32, device=dev)
-    # [ (A o W)^T | G | bvec, pad ]: the data gradient's weight operand, rows of N + Cx + 8 elements
-    wcat = torch.empty((Cx, N + Cx + 8), dtype=dt, device=dev)
-    ax = torch.empty((Cx + 8, N), dtype=dt, device=dev)               # (B o W)^T ; K ; 0
+    wt_scaled = torch.empty((Cx, N), dtype=dt, device=dev)            # (A o W)^T: the data gradient's first weight operand
+    bw = torch.empty((N, Cx + 8), dtype=dt, device=dev)               # (B o W | K | 0), output-channel major
     g32 = _f32(gamma.detach())
     box = {}
 
@@ -433,7 +437,7 @@ def _conv_bn_fold_backward(ctx, fent):
         gv, gb = box["g"]
         C().bnfold_coeffs(raw.data_ptr(), wlp.data_ptr(), Cx, dbeta_sum.data_ptr(), coef[0].data_ptr(),
                           coef[1].data_ptr(), g32.data_ptr(), float(count), N, Cx, gv.data_ptr(), float(gb),
-                          view.data_ptr(), float(beta), abk.data_ptr(), wcat.data_ptr(), N + Cx + 8, ax.data_ptr(), _dt(a), st)
+                          view.data_ptr(), float(beta), abk.data_ptr(), wt_scaled.data_ptr(), N, bw.data_ptr(), _dt(a), st)
 
     # (gamma's view is only noted; the kernel that fills both runs when beta's is known)
     sg, sb = grad_sink.sink_of(gamma), grad_sink.sink_of(beta_p)
@@ -454,14 +458,12 @@ def _conv_bn_fold_backward(ctx, fent):
     one = _tap_table(dev, ((0, 0, 0),))
     dx = None
     if ctx.needs_input_grad[0] and ctx.geom[3]:
-        # ---- G = W^T diag(B) W and bvec = K^T W in one small GEMM: out[c2][c1] = sum_n W[n][c2] ax[c1][n], written
-        #      behind (A o W)^T so that [ (A o W)^T | G ] is ONE weight operand with rows of N + Cx (+ 8) elements
-        wt = conv_weight_t(weight, dt)                                # [Cx][N]
-        ldw = N + Cx + 8
-        _igemm(wt, ax, wcat[:, N:], None, None, one, Cx, Cx + 8, N, 1, N, N, ldw, 1, Cx, 1, 1, 1, Cx, dtype=dt,
-               out_dtype=dt)
-        bvec = wcat[:, N + Cx].float().contiguous()
-        # ---- da = [dy_m | a] [ (A o W)^T | G ]^T + bvec in one launch, with the usual fused reduction for the BN before
+        # ---- G = W^T diag(B) W and bvec = K^T W: a reduction over the N output channels with both operands stored
+        #      channel-major -- the shape of a weight gradient with N "pixels" (split across workgroups; as an ordinary
+        #      GEMM it was one or two workgroups walking all of K: 69 us per call)
+        gk = _wgrad_raw(wlp, bw, N, Cx, Cx + 8, 1, N, out_dtype=dt, ldy=Cx, ldx=Cx + 8)        # [Cx][Cx + 8]
+        bvec = gk[:, Cx].float().contiguous()
+        # ---- da = dy_m (A o W) + a G + bvec in one launch (two gathered operands back to back), with the usual fused reduction for the BN before
         src, ctx.bnsrc = ctx.bnsrc, None
         bnred = slab = None
         if src is not None and src.uses == 1 and src.mode != 1:
@@ -469,8 +471,8 @@ def _conv_bn_fold_backward(ctx, fent):
             rows = C().igemm_stats_rows(M, Cx, N, 1, _dt(dy), _dt(dy))
             slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dev)
         dx = torch.empty((NB, IH, IW, Cx), dtype=dt, device=dev)
-        _igemm(dy, wcat, dx, bvec, slab, one, M, Cx, N, 1, N, ldw, Cx, IH, IW, 1, 1, IH, IW, dtype=dt, out_dtype=dt,
-               bnred=bnred, cat=(a, Cx, Cx))
+        _igemm(dy, wt_scaled, dx, bvec, slab, one, M, Cx, N, 1, N, N, Cx, IH, IW, 1, 1, IH, IW, dtype=dt, out_dtype=dt,
+               bnred=bnred, cat=(a, Cx, Cx, gk, Cx + 8))
         if slab is not None:
             _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version, bool(bnred[4]))
     # ---- weight gradient: A o raw + B o (W gram) + K (x) cs, W gram in fp32 (the terms cancel)
