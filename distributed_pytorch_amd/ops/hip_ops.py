@@ -96,6 +96,7 @@ def bump_generation() -> None:
     _pending_mask.clear()
     _pending_compact.clear()
     _pending_fold.clear()
+    _pending_colsum.clear()
 
 
 class _WCache:
@@ -349,6 +350,9 @@ _BN_FOLD_MIN_MB = float(os.environ.get("DPA_BN_FOLD_MIN_MB", "300"))
 # slab with sum dy_m per part, BN coef [4][N], gamma, beta parameter, count, generation).  Consumed by _ConvFn.backward of
 # the 1x1 convolution that produced the BatchNorm's input.
 _pending_fold: Dict[int, tuple] = {}
+# data_ptr of a MASKED block-output gradient handed on to the residual branch -> (partial slab whose first row holds its
+# column sums per 128-row part, version, generation)
+_pending_colsum: Dict[int, tuple] = {}
 bn_fold_counts = {"folded": 0}
 
 
@@ -358,14 +362,14 @@ def _bn_fold_eligible(x, weight, bias, stride, padding, relu, want_stats, needs_
     if not (torch.is_grad_enabled() and x.is_cuda and x.requires_grad and weight.requires_grad):
         return False
     K, Cw, R, S = weight.shape
-    if (R, S) != (1, 1) or tuple(stride) != (1, 1) or tuple(padding) != (0, 0):
+    if (R, S) != (1, 1) or tuple(padding) != (0, 0) or tuple(stride) not in ((1, 1), (2, 2)):
         return False
     if x.dtype not in (torch.bfloat16, torch.float16) or weight.dtype != torch.float32 or x.dim() != 4:
         return False
     Cx = x.shape[-1]
     if Cx != Cw or Cx % 64 or K % 64 or K < _BN_FOLD_MIN_RATIO * Cx:
         return False
-    if x.numel() // Cx * K * x.element_size() < _BN_FOLD_MIN_MB * 2 ** 20:
+    if x.numel() // Cx // (stride[0] * stride[1]) * K * x.element_size() < _BN_FOLD_MIN_MB * 2 ** 20:
         return False
     return grad_sink.sink_of(weight) is not None
 
@@ -408,6 +412,11 @@ def _conv_bn_fold_backward(ctx, fent):
     see csrc/kernels/bnfold.hip for the algebra.  `fent` comes from _BNFn.backward, `ctx` is the convolution's."""
     _, dy, part, coef, gamma, beta_p, count, _ = fent
     a, weight, _ = ctx.saved_tensors
+    full_shape = tuple(a.shape)
+    (sh, sw) = ctx.geom[0]
+    if (sh, sw) != (1, 1):
+        # strided 1x1 branch: everything below is a dense problem on the pixels the convolution really read
+        a = a[:, ::sh, ::sw, :].contiguous()
     NB, IH, IW, Cx = a.shape
     N = weight.shape[0]
     M = NB * IH * IW
@@ -475,6 +484,14 @@ def _conv_bn_fold_backward(ctx, fent):
                bnred=bnred, cat=(a, Cx, Cx, gk, Cx + 8))
         if slab is not None:
             _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version, bool(bnred[4]))
+        if (sh, sw) != (1, 1):
+            if ctx.compact:
+                # the owner of the alias this branch read adds a COMPACT gradient in its own epilogue (see _ConvFn.backward)
+                fake = torch.full((1,), float("nan"), dtype=dt, device=dev)
+                dxc, dx = dx, fake.expand(full_shape)
+                _pending_compact[dx.data_ptr()] = (fake, dxc, (sh, sw), _generation, full_shape)
+            else:
+                dx = _expand_compact((None, dx, (sh, sw), _generation, full_shape))
     # ---- weight gradient: A o raw + B o (W gram) + K (x) cs, W gram in fp32 (the terms cancel)
     if ctx.needs_input_grad[1]:
         wg = torch.empty((N, Cx), dtype=torch.float32, device=dev)
@@ -1378,6 +1395,7 @@ class _BNFn(torch.autograd.Function):
             ctx.bias_ref = bias
             ctx.lazy_res = False
             ctx.cfg = (0, False, group, count)
+            ctx.fold = fold_ok          # (its gradient is the block's masked output gradient: see _pending_colsum)
             _BNFn.last = None
             _BNFn.deferred = coef
             _BNFn.deferred_relu = False
@@ -1430,6 +1448,12 @@ class _BNFn(torch.autograd.Function):
                 relu, y = 3, ent[0]
             else:
                 dy = apply_bit_mask(dy, ent[0])
+        shared = _pending_colsum.pop(dy.data_ptr(), None)
+        if shared is not None and ctx.fold and relu == 0 and not has_res and dy.is_contiguous() \
+                and shared[1] == dy._version and shared[2] == _generation and ctx.needs_input_grad[0]:
+            token = torch.full((1,), float("nan"), dtype=dy.dtype, device=x.device).expand(x.shape)
+            _pending_fold[token.data_ptr()] = (token, dy, shared[0], coef, weight, ctx.bias_ref, count, _generation)
+            return token, None, None, None, None, None, None, None, None, None, None, None, None, None
         dy = dy if dy.is_contiguous() else dy.contiguous()
         Cc = x.shape[-1]
         M = x.numel() // Cc
@@ -1442,6 +1466,10 @@ class _BNFn(torch.autograd.Function):
                 token = torch.full((1,), float("nan"), dtype=dy.dtype, device=dev).expand(x.shape)
                 _pending_fold[token.data_ptr()] = (token, dy, fused[0], coef, weight, ctx.bias_ref, count, _generation)
                 dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+                if dres is not None:
+                    # the residual branch receives the very same masked tensor: an activation-free BatchNorm there (the
+                    # downsample branch) can fold too, with the same column sums
+                    _pending_colsum[dy.data_ptr()] = (fused[0], dy._version, _generation)
                 return token, None, None, dres, None, None, None, None, None, None, None, None, None, None
             fused = None            # (a masked gradient is still a valid input of the ordinary path: masking is idempotent)
         if fused is not None and fused[1] == x.data_ptr() and fused[2] == dy._version:

@@ -17,10 +17,22 @@ from _gpu_util import assert_close  # noqa: E402
 DEV = "cuda"
 
 
+from distributed_pytorch_amd.models.resnet import conv1x1  # noqa: E402
+from distributed_pytorch_amd.nn import BatchNorm2d  # noqa: E402
+
+
 class Stack(torch.nn.Module):
-    def __init__(self, planes=64, blocks=3):
+    """Three bottlenecks; ``stride`` > 0: the first one changes width (and resolution) through a downsample branch."""
+
+    def __init__(self, planes=64, blocks=3, stride=0):
         super().__init__()
-        self.blocks = torch.nn.ModuleList([Bottleneck(planes * 4, planes) for _ in range(blocks)])
+        self.cin = planes * 4
+        first = Bottleneck(planes * 4, planes)
+        if stride:
+            self.cin = planes * 2
+            down = torch.nn.Sequential(conv1x1(self.cin, planes * 4, stride), BatchNorm2d(planes * 4))
+            first = Bottleneck(self.cin, planes, stride, down)
+        self.blocks = torch.nn.ModuleList([first] + [Bottleneck(planes * 4, planes) for _ in range(blocks - 1)])
 
     def forward(self, x):
         for b in self.blocks:
@@ -28,9 +40,9 @@ class Stack(torch.nn.Module):
         return x
 
 
-def _run(fold, planes, shape, seed=0):
+def _run(fold, planes, shape, seed=0, stride=0):
     torch.manual_seed(seed)
-    net = Stack(planes).to(DEV).train()
+    net = Stack(planes, stride=stride).to(DEV).train()
     for m in net.modules():           # non-trivial BN parameters
         if hasattr(m, "running_mean") and m.weight is not None and m.weight.dim() == 1:
             with torch.no_grad():
@@ -39,8 +51,9 @@ def _run(fold, planes, shape, seed=0):
     opt = FusedSGD(net.parameters(), lr=0.0, momentum=0.0)
     net, opt = amp.initialize(net, opt, opt_level="O2", dtype="bf16")
     N, H, W = shape
-    x = (torch.randn(N, H, W, planes * 4, device=DEV).relu() + 0.1).to(torch.bfloat16).requires_grad_(True)
-    gy = torch.randn(N, H, W, planes * 4, device=DEV).to(torch.bfloat16)
+    x = (torch.randn(N, H, W, net.cin, device=DEV).relu() + 0.1).to(torch.bfloat16).requires_grad_(True)
+    st = max(stride, 1)
+    gy = torch.randn(N, (H + st - 1) // st, (W + st - 1) // st, planes * 4, device=DEV).to(torch.bfloat16)
     old, old_mb = hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB
     hip_ops._BN_FOLD = fold
     hip_ops._BN_FOLD_MIN_MB = 0.0           # (the default leaves tensors this small to the ordinary backward)
@@ -56,11 +69,13 @@ def _run(fold, planes, shape, seed=0):
     return net, x, gy, y.detach().float(), x.grad.detach().float(), grads, hip_ops.bn_fold_counts["folded"]
 
 
-@pytest.mark.parametrize("planes,shape", [(64, (4, 14, 14)), (128, (3, 9, 11))])
-def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, shape):
-    net, x, gy, y1, dx1, g1, folded = _run(True, planes, shape)
-    _, _, _, y0, dx0, g0, none = _run(False, planes, shape)
-    assert folded == 2 and none == 0          # blocks 0 and 1: their bn3 receives a fused, pre-masked gradient
+@pytest.mark.parametrize("planes,shape,stride", [(64, (4, 14, 14), 0), (128, (3, 9, 11), 0), (64, (4, 14, 14), 1),
+                                                 (64, (3, 14, 18), 2)])
+def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, shape, stride):
+    net, x, gy, y1, dx1, g1, folded = _run(True, planes, shape, stride=stride)
+    _, _, _, y0, dx0, g0, none = _run(False, planes, shape, stride=stride)
+    # blocks 0 and 1: their bn3 receives a fused, pre-masked gradient; with a downsample branch its BatchNorm folds too
+    assert folded == (3 if stride else 2) and none == 0
     assert torch.equal(y1, y0)
     # fp32 reference with the SAME (bf16-rounded) weights and input
     def ref_block(blk, t):
@@ -88,9 +103,12 @@ def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, sha
                 o = o + res
             return TF.relu(o) if relu else o
         pre = "blocks.%d." % i
+        idt = t
+        if blk.downsample is not None:
+            idt = cbr(t, pre + "downsample.0", pre + "downsample.1", blk.downsample[0], blk.downsample[1], False)
         o = cbr(t, pre + "conv1", pre + "bn1", blk.conv1, blk.bn1, True)
         o = cbr(o, pre + "conv2", pre + "bn2", blk.conv2, blk.bn2, True)
-        t = cbr(o, pre + "conv3", pre + "bn3", blk.conv3, blk.bn3, True, t)
+        t = cbr(o, pre + "conv3", pre + "bn3", blk.conv3, blk.bn3, True, idt)
     t.backward(gy.float().permute(0, 3, 1, 2))
     # The network runs bf16 activations through three blocks (ReLU masks flip, roundings accumulate): per-element bounds
     # against an fp32 reference are meaningless here.  Tensor-level: the fold differs from the ordinary backward by
