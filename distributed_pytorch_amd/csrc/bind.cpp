@@ -108,6 +108,18 @@ PYBIND11_MODULE(_C, m) {
   m.def("igemm_force_config", &igemm_force_config);
   m.def("igemm_num_configs", &igemm_num_configs);
 
+  m.def("wgrad_row3_splits", [](int NB, int H, int W, int N, int Cred, int R, int dtype) {
+    int rps = 0;
+    const int s = wgrad_row3_splits(NB, H, W, N, Cred, R, dtype, &rps);
+    return std::make_pair(s, rps);
+  });
+  m.def("wgrad_row3", [](uintptr_t dY, uintptr_t X, uintptr_t slab, int NB, int H, int W, int N, int Cred, int R, int ph,
+                         int ldy, int ldx, int splits, int rps, int dtype, uintptr_t s) {
+    wgrad_row3_launch(ptr<const void>(dY), ptr<const void>(X), ptr<float>(slab), NB, H, W, N, Cred, R, ph, ldy, ldx, splits,
+                      rps, dtype, st(s));
+  });
+  m.def("wgrad_row3_set_mode", &wgrad_row3_set_mode);
+  m.def("wgrad_row3_set_variant", &wgrad_row3_set_variant);
   m.def("wgrad_force_config", &wgrad_force_config);
   m.def("wgrad_num_configs", &wgrad_num_configs);
   m.def("wgrad_set_target_blocks", &wgrad_set_target_blocks);

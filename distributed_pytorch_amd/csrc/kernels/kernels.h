@@ -131,6 +131,16 @@ void wgrad_force_config(int cfg);   // tuning hook, -1 = automatic
 int wgrad_num_configs();
 void wgrad_set_target_blocks(int n);   // tuning hook: workgroups the pixel split aims for
 
+// ------------------------------------------------------------------------------ wgrad_row3.hip
+// Filter-row weight gradient (R x 3, stride 1, "same"): one staged activation row tile serves the three taps of a filter
+// row.  wgrad_row3_splits() == 0: not covered (image width > 64, fp32, channels not a multiple of 64): use wgrad_launch.
+// Slab layout [splits][N][R*3*Cred] as wgrad_launch writes it.
+int wgrad_row3_splits(int NB, int H, int W, int N, int Cred, int R, int dtype, int* rows_per_split);
+void wgrad_row3_launch(const void* dY, const void* X, float* slab, int NB, int H, int W, int N, int Cred, int R, int ph,
+                       int ldy, int ldx, int splits, int rows_per_split, int dtype, hipStream_t stream);
+void wgrad_row3_set_mode(int mode);
+void wgrad_row3_set_variant(int v);   // -1 automatic, 0 never
+
 // ------------------------------------------------------------------------------ bn.hip
 // x, y, residual, dy, dx: [M][C] (NHWC flattened), stats fp32.
 int bn_partial_rows(long M, int C);

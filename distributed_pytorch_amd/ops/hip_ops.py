@@ -40,6 +40,7 @@ def C():
         _C.igemm_set_nt_store(int(os.environ.get("DPA_IGEMM_NT", "0")))  # 0: by size, 1: always, -1: never
         _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
         # convolutions on the 256 x 256 multi-phase pipeline (csrc/kernels/conv8.hip): -1 auto, 0 off, 1 / 2 forced
+        _C.wgrad_row3_set_mode(int(os.environ.get("DPA_WGRAD_ROW3", "-1")))     # filter-row weight gradient: -1 auto, 0 off
         _C.conv8_set_mode(int(os.environ.get("DPA_CONV8", "-1")))
         _C.conv8_set_min_k(int(os.environ.get("DPA_CONV8_MIN_K", "512")))
         _C.conv8_set_tail_split(int(os.environ.get("DPA_CONV8_TAIL", "4")))
@@ -846,13 +847,22 @@ def conv_wgrad(dy, x, weight, stride, padding, axf=None):
     OH, OW = dy.shape[1], dy.shape[2]
     M = NB * OH * OW
     Ktot = R * S * Cx
-    splits, pps = C().wgrad_choose_splits(M, K, Ktot, _dt(dy))
-    slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
-    taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
     st = _stream()
-    C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
-              sh, sw, OH, OW, splits, pps, 1 if (R * S == 1 and ph == 0 and pw == 0) else 0, _dt(dy), st,
-              1, 0, 0, axf[2].data_ptr() if axf is not None else 0, axf[3].data_ptr() if axf is not None else 0)
+    splits = 0
+    if S == 3 and (sh, sw) == (1, 1) and pw == 1 and (OH, OW) == (IH, IW) and axf is None and x.is_contiguous():
+        # filter-row kernel: one staged activation row tile per filter ROW instead of per tap (csrc/kernels/wgrad_row3.hip)
+        splits, rps = C().wgrad_row3_splits(NB, IH, IW, K, Cx, R, _dt(dy))
+    if splits > 0:
+        slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
+        C().wgrad_row3(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), NB, IH, IW, K, Cx, R, ph, K, Cx, splits, rps,
+                       _dt(dy), st)
+    else:
+        splits, pps = C().wgrad_choose_splits(M, K, Ktot, _dt(dy))
+        slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
+        taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
+        C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
+                  sh, sw, OH, OW, splits, pps, 1 if (R * S == 1 and ph == 0 and pw == 0) else 0, _dt(dy), st,
+                  1, 0, 0, axf[2].data_ptr() if axf is not None else 0, axf[3].data_ptr() if axf is not None else 0)
     gdtype = weight.dtype
     sink = grad_sink.sink_of(weight)
     if Cx == Cw and sink is not None and _flat_same_layout(sink.view, weight) \
