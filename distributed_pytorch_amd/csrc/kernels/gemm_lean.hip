@@ -52,6 +52,28 @@ template <> struct LeanMma<f16_t> {
   }
 };
 
+// ---- packed bf16 pair arithmetic for the streaming epilogues (v_pk_add_f32 / v_pk_fma_f32 / v_cvt_pk_bf16_f32): the
+// epilogue of a fused accumulate + BN-backward launch was VALU bound at ~22 instructions per element when every element
+// went through scalar get / select / set (bench/experiments/lean_racc_ablate.py); pairs take ~8.
+__device__ __forceinline__ f32x2_t unpack_bf16x2(uint32_t w) {
+  f32x2_t x;
+  x.x = __uint_as_float(w << 16);
+  x.y = __uint_as_float(w & 0xffff0000u);
+  return x;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2_t y) {
+  const bf16x2_t p = __builtin_convertvector(y, bf16x2_t);
+  uint32_t r;
+  __builtin_memcpy(&r, &p, 4);
+  return r;
+}
+// bits 2j, 2j+1 of a mask byte -> an AND mask for the bf16 pair j (low half = element 2j)
+__device__ __forceinline__ uint32_t pair_mask(uint32_t bits, int j) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * j, 1);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * j + 1, 1);
+  return (lo & 0x0000ffffu) | (hi & 0xffff0000u);        // v_bfi_b32
+}
+
 int g_lean_abl = 0;     // debug ablation of the plain variant (scratch/lean_ablate.py)
 int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 force 128-byte K tiles
 
@@ -331,6 +353,14 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   const int lsy = rstr ? __builtin_ctz((unsigned)p.OSY) : 0, lsx = rstr ? __builtin_ctz((unsigned)p.OSX) : 0;
   const uint8_t* const xmask = (BNB && bn_mode == 3) ? reinterpret_cast<const uint8_t*>(p.bn_z) : nullptr;
   auto prefetch = [&](int half, Pre& q) __attribute__((always_inline)) {
+    if (ABL == 7) {                     // ablation: the epilogue's extra operands are never requested
+#pragma unroll
+      for (int i = 0; i < EH; ++i) {
+        q.r[i] = q.x[i] = u32x4_t{0u, 0u, 0u, 0u};
+        q.rbits[i] = q.xbits[i] = 0xffu;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < EH; ++i) {
       const int it = half * EH + i;
@@ -373,6 +403,25 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       }
     }
   };
+  // per-channel coefficients of the BN-backward sums, requested BEFORE the half-tile prefetches: vmcnt retires in
+  // order, a load issued behind prefetch(1) would make the first half wait for the second half's operands (that
+  // cost 20 % of the fused accumulate + reduction launches, bench/experiments/lean_racc_ablate.py).  kIgemmBnFold
+  // sums dz_m only and needs none.
+  float bmu[VEC], bis[VEC], bsc[VEC], bsh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) bmu[j] = bis[j] = bsc[j] = bsh[j] = 0.f;
+  if constexpr (BNB) {
+    if (!bn_fold) {
+      const float* cf = p.bn_coef + n0 + ce * VEC;          // [4][N]: mean, invstd, scale, shift
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        bmu[j] = cf[j];
+        bis[j] = cf[p.N + j];
+        bsc[j] = bn_mode == 2 ? cf[2 * p.N + j] : 0.f;
+        bsh[j] = bn_mode == 2 ? cf[3 * p.N + j] : 0.f;
+      }
+    }
+  }
   Pre q0, q1;
   if constexpr (RACC || BNB) prefetch(0, q0);
   const bool relu_out = BIAS && (p.flags & kIgemmRelu);
@@ -410,25 +459,52 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) kshift[j] = k0.get(j);
   }
-  float bmu[VEC], bis[VEC], bsc[VEC], bsh[VEC];
-  if constexpr (BNB) {
-    const float* cf = p.bn_coef + n0 + ce * VEC;          // [4][N]: mean, invstd, scale, shift
+  const bool nt_store = p.flags & kIgemmNtStore;
+  // packed accumulators of the bf16 BN-backward epilogue (pair j = channels 2j, 2j+1 of the chunk)
+  f32x2_t s1p[VEC / 2], s2p[VEC / 2], bisp[VEC / 2], nbp[VEC / 2];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      bmu[j] = cf[j];
-      bis[j] = cf[p.N + j];
-      bsc[j] = bn_mode == 2 ? cf[2 * p.N + j] : 0.f;
-      bsh[j] = bn_mode == 2 ? cf[3 * p.N + j] : 0.f;
+  for (int j = 0; j < VEC / 2; ++j) {
+    s1p[j] = s2p[j] = f32x2_t{0.f, 0.f};
+    bisp[j] = nbp[j] = f32x2_t{0.f, 0.f};
+    if constexpr (BNB) {
+      bisp[j] = f32x2_t{bis[2 * j], bis[2 * j + 1]};
+      nbp[j] = f32x2_t{-bmu[2 * j] * bis[2 * j], -bmu[2 * j + 1] * bis[2 * j + 1]};      // xhat = x * invstd - mean * invstd
     }
   }
-  const bool nt_store = p.flags & kIgemmNtStore;
-  auto process = [&](int half, const Pre& q, auto mode_c) __attribute__((always_inline)) {
+  auto process = [&](int half, const Pre& q, auto mode_c, auto fold_c) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_c)::value;
+    constexpr bool FOLD = decltype(fold_c)::value;
 #pragma unroll
     for (int i = 0; i < EH; ++i) {
       const int it = half * EH + i;
       const int row = er0 + it * RPE;
       if (row >= rows) continue;
+      char* dst = Cg + (coff0 + (uint32_t)it * cstep);
+      if constexpr (BNB && !STATS && MODE != 2 && TypeInfo<T>::kCode == kBF16) {
+        // bf16, mask absent (0: xbits = 0xff) or as bits (3): whole pairs at a time
+        const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(se + row * LDE + ce * 16);
+        u32x4_t o;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          uint32_t w = vv[pr];
+          if constexpr (RACC) {
+            const uint32_t rm = q.r[i][pr] & pair_mask(q.rbits[i], pr);
+            w = pack_bf16x2(unpack_bf16x2(w) + unpack_bf16x2(rm));
+          }
+          const uint32_t wm = w & pair_mask(q.xbits[i], pr);
+          o[pr] = FOLD ? wm : w;              // the gradient leaves already masked under kIgemmBnFold
+          const f32x2_t d = unpack_bf16x2(wm);      // the values as stored (rounded to T), masked
+          s1p[pr] += d;
+          if constexpr (!FOLD) {
+            const f32x2_t xh = unpack_bf16x2(q.x[i][pr]) * bisp[pr] + nbp[pr];
+            s2p[pr] += d * xh;
+          }
+        }
+        if (ABL == 4) asm volatile("" ::"v"(o));
+        else if (nt_store) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst));
+        else *reinterpret_cast<u32x4_t*>(dst) = o;
+        continue;
+      }
       Vec16<T> v;
       v.load(se + row * LDE + ce * 16);
       if constexpr (RACC) {
@@ -437,9 +513,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (((q.rbits[i] >> j) & 1u) ? r.get(j) : 0.f));
       }
-      char* dst = Cg + (coff0 + (uint32_t)it * cstep);
       if constexpr (BNB) {
-        if (bn_fold && MODE == 3) {       // the gradient leaves already masked (kIgemmBnFold)
+        if (FOLD && MODE == 3) {       // the gradient leaves already masked (kIgemmBnFold)
 #pragma unroll
           for (int j = 0; j < VEC; ++j)
             if (!((q.xbits[i] >> j) & 1u)) v.set(j, 0.f);
@@ -475,25 +550,53 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       }
     }
   };
+  using std::integral_constant;
   if (bn_mode == 3) {
-    process(0, q0, std::integral_constant<int, 3>());
-    process(1, q1, std::integral_constant<int, 3>());
+    if (bn_fold) {
+      process(0, q0, integral_constant<int, 3>(), integral_constant<bool, true>());
+      process(1, q1, integral_constant<int, 3>(), integral_constant<bool, true>());
+    } else {
+      process(0, q0, integral_constant<int, 3>(), integral_constant<bool, false>());
+      process(1, q1, integral_constant<int, 3>(), integral_constant<bool, false>());
+    }
   } else if (bn_mode == 2) {
-    process(0, q0, std::integral_constant<int, 2>());
-    process(1, q1, std::integral_constant<int, 2>());
+    process(0, q0, integral_constant<int, 2>(), integral_constant<bool, false>());
+    process(1, q1, integral_constant<int, 2>(), integral_constant<bool, false>());
+  } else if (bn_fold) {
+    process(0, q0, integral_constant<int, 0>(), integral_constant<bool, true>());
+    process(1, q1, integral_constant<int, 0>(), integral_constant<bool, true>());
   } else {
-    process(0, q0, std::integral_constant<int, 0>());
-    process(1, q1, std::integral_constant<int, 0>());
+    process(0, q0, integral_constant<int, 0>(), integral_constant<bool, false>());
+    process(1, q1, integral_constant<int, 0>(), integral_constant<bool, false>());
   }
-  if constexpr (STATS || BNB) {
+#pragma unroll
+  for (int j = 0; j < VEC / 2; ++j) {
+    s1[2 * j] += s1p[j].x; s1[2 * j + 1] += s1p[j].y;
+    s2[2 * j] += s2p[j].x; s2[2 * j + 1] += s2p[j].y;
+  }
+  if constexpr ((STATS || BNB) && ABL != 8) {
+    if (ABL == 10) {                    // ablation: the sums are accumulated but never reduced
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) t += s1[j] + s2[j];
+      if (t == 12345.678f) p.stats[0] = t;
+      return;
+    }
     // threads sharing a chunk column: tid = ce (mod CE): reduce inside the wave, then over waves
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
 #pragma unroll
       for (int o = 32; o >= CE; o >>= 1) {
         s1[j] += __shfl_xor(s1[j], o, 64);
-        s2[j] += __shfl_xor(s2[j], o, 64);
+        if (!bn_fold) s2[j] += __shfl_xor(s2[j], o, 64);       // (fold: the second row is all zeros)
       }
+    }
+    if (ABL == 11) {                    // ablation: reduced inside the wave, not over the waves
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) t += s1[j] + s2[j];
+      if (t == 12345.678f) p.stats[0] = t;
+      return;
     }
     // LDS-only barrier: __syncthreads() would first drain the tile's global stores (vmcnt(0))
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -514,11 +617,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
     const int sld = p.stats_ld;
     if constexpr (BNB) {
       // BatchNorm-backward partials of this tile: (sum dz_m, sum dz_m * xhat)
-      for (int c = tid; c < 2 * BN; c += 256) {
+      for (int c = tid; c < (bn_fold ? BN : 2 * BN); c += 256) {       // (fold: the consumer never reads the second row)
         const int which = c / BN, col = c - which * BN;
         const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
                         red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
-        p.stats[((size_t)mt * 2 + which) * sld + n0 + col] = s;
+        if (ABL == 9) asm volatile("" ::"v"(s));
+        else p.stats[((size_t)mt * 2 + which) * sld + n0 + col] = s;
       }
     } else {
       const float nt_rows = (float)rows;
@@ -583,6 +687,21 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
     if (stats) launch_lean<T, BN, BKB, MINB, PF, true, false, false, true>(p, stream);
     else launch_lean<T, BN, BKB, MINB, PF, false, false, false, true>(p, stream);
   } else if (bnb) {
+#ifdef DPA_LEAN_ABLATE
+    if constexpr (BN == 128 && sizeof(T) == 2) {
+      if (racc) switch (g_lean_abl) {
+        case 3: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 3>(p, stream); return;
+        case 4: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 4>(p, stream); return;
+        case 5: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 5>(p, stream); return;
+        case 7: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 7>(p, stream); return;
+        case 8: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 8>(p, stream); return;
+        case 9: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 9>(p, stream); return;
+        case 10: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 10>(p, stream); return;
+        case 11: launch_lean<T, BN, BKB, MINB, PF, false, true, true, false, 11>(p, stream); return;
+        default: break;
+      }
+    }
+#endif
     if (racc) launch_lean<T, BN, BKB, MINB, PF, false, true, true, false>(p, stream);
     else launch_lean<T, BN, BKB, MINB, PF, false, false, true, false>(p, stream);
   } else if (stats) {

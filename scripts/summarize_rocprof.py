@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 --kernel-trace --stats CSV directory into a short markdown table.
-usage: summarize_rocprof.py <dir with *_kernel_stats.csv> <steps profiled> [title] > profiles/x.md"""
+usage: summarize_rocprof.py <dir with *_kernel_stats.csv> <steps profiled> [title] [rows, default 30] > profiles/x.md"""
 import csv
 import glob
 import os
@@ -18,12 +18,16 @@ def main():
         os.path.basename(f), steps, tot / 1e6, tot / 1e6 / steps))
     print("| kernel | calls/step | avg us | ms/step | % |")
     print("|---|---|---|---|---|")
-    for r in rows[:30]:
+    top = int(sys.argv[4]) if len(sys.argv) > 4 else 30
+    for r in rows[:top]:
         name = r["Name"].replace("dpa::(anonymous namespace)::", "").replace("void ", "")
         name = name.split("(")[0][:90]
         t = float(r["TotalDurationNs"])
         print("| `%s` | %.1f | %.1f | %.3f | %.1f |" % (name, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
                                                     t / 1e6 / steps, 100 * t / tot))
+    rest = sum(float(r["TotalDurationNs"]) for r in rows[top:])
+    if rest:
+        print("| (%d more kernels) | | | %.3f | %.1f |" % (len(rows) - top, rest / 1e6 / steps, 100 * rest / tot))
 
 
 if __name__ == "__main__":
