@@ -81,10 +81,13 @@ int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 fo
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
 // CAT: the reduction runs over two gathered operands back to back (IgemmParams::A2): when the K tiles of the first are
 // used up the staging base and the per-row offsets switch to the second, nothing else in the loop changes.
+// FOLD: the BNB launch is a kIgemmBnFold one (masked store, sum dz_m only): the BN input and the coefficients are never
+// requested -- compiled apart because their registers decide between 3 and 4 workgroups per CU.
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false, bool AXF = false, bool CAT = false>
+          bool BIAS = false, bool AXF = false, bool CAT = false, bool FOLD = false>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
+  static_assert(!FOLD || BNB, "FOLD is a BNB launch");
   constexpr int BM = 128;
   constexpr int VEC = 8;
   constexpr int BK = BKB / 2;
@@ -163,24 +166,28 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   // BIAS (Linear layers): the accumulators START at the bias of their channel -- register r of lane half lh is channel
   // (r&3) + 8*(r>>2) + 4*lh of the 32-block -- so the epilogue has nothing to add (one fp32 rounding, as in the
   // general kernel; only the order of the fp32 additions differs).
+  // (called BEHIND the first tile's requests: in front of them the bias load's latency would be paid before the
+  // pipeline starts)
   f32x16_t acc[NI][MI];
+  auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int a = 0; a < NI; ++a) {
-    float bv[16];
+    for (int a = 0; a < NI; ++a) {
+      float bv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = 0.f;
-    if constexpr (BIAS) {
+      for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+      if constexpr (BIAS) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + wn * WTN + a * 32 + 8 * g + 4 * lh);
-        bv[4 * g + 0] = b4.x; bv[4 * g + 1] = b4.y; bv[4 * g + 2] = b4.z; bv[4 * g + 3] = b4.w;
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + wn * WTN + a * 32 + 8 * g + 4 * lh);
+          bv[4 * g + 0] = b4.x; bv[4 * g + 1] = b4.y; bv[4 * g + 2] = b4.z; bv[4 * g + 3] = b4.w;
+        }
       }
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = bv[r];
     }
-#pragma unroll
-    for (int b = 0; b < MI; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = bv[r];
-  }
+  };
 
   // PF register sets: PF K tiles are in flight while one is consumed (a K step computes for ~300 cycles, a load
   // takes 1-2k under load: with one tile in flight every K step pays most of a memory latency)
@@ -280,6 +287,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   int kt = 0;
   if constexpr (PF == 1) {
     load_tile(0);
+    init_acc();
     store_tile(0, 0);
     loop_sync();
     for (; kt + 2 <= nk; kt += 2) {
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   } else {
     load_tile(0);
     if (nk > 1) load_tile(1);
+    init_acc();
     store_tile(0, 0);
     loop_sync();
     for (; kt + 2 <= nk; kt += 2) {
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   };
   const int bn_mode = BNB ? (p.bn_relu & 3) : 0;   // 0 no ReLU, 2 mask recomputed from the BN input, 3 bit mask
   const bool bn_clip = BNB && (p.bn_relu & 4);     // ReLU6: the recomputed mask is 0 < y < 6
-  const bool bn_fold = BNB && (p.flags & kIgemmBnFold);   // masked store, sum dz_m only, bn_x not read (kernels.h)
+  constexpr bool bn_fold = FOLD;                     // masked store, sum dz_m only, bn_x not read (kernels.h)
   const char* const Rg = reinterpret_cast<const char*>(p.R) + cbase;
   const char* const Xg = reinterpret_cast<const char*>(p.bn_x) + cbase;
   const uint8_t* const rmask = RACC ? p.r_mask : nullptr;
@@ -387,19 +396,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       }
       if constexpr (BNB) q.xbits[i] = xmask != nullptr ? xmask[(cbase + off) >> 4] : 0xffu;
     }
-    if constexpr (BNB) {
-      // (its own loop under ONE uniform branch: a per-load condition makes the compiler wait for every load in turn)
-      if (!bn_fold) {
+    if constexpr (BNB && !FOLD) {
 #pragma unroll
-        for (int i = 0; i < EH; ++i) {
-          const int it = half * EH + i;
-          const bool ok = er0 + it * RPE < rows;
-          const uint32_t off = ok ? coff0 + (uint32_t)it * cstep : (uint32_t)(ce * 16);
-          q.x[i] = *reinterpret_cast<const u32x4_t*>(Xg + off);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < EH; ++i) q.x[i] = u32x4_t{0u, 0u, 0u, 0u};
+      for (int i = 0; i < EH; ++i) {
+        const int it = half * EH + i;
+        const bool ok = er0 + it * RPE < rows;
+        const uint32_t off = ok ? coff0 + (uint32_t)it * cstep : (uint32_t)(ce * 16);
+        q.x[i] = *reinterpret_cast<const u32x4_t*>(Xg + off);
       }
     }
   };
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   float bmu[VEC], bis[VEC], bsc[VEC], bsh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) bmu[j] = bis[j] = bsc[j] = bsh[j] = 0.f;
-  if constexpr (BNB) {
-    if (!bn_fold) {
+  if constexpr (BNB && !FOLD) {
+    {
       const float* cf = p.bn_coef + n0 + ce * VEC;          // [4][N]: mean, invstd, scale, shift
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -471,9 +474,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       nbp[j] = f32x2_t{-bmu[2 * j] * bis[2 * j], -bmu[2 * j + 1] * bis[2 * j + 1]};      // xhat = x * invstd - mean * invstd
     }
   }
-  auto process = [&](int half, const Pre& q, auto mode_c, auto fold_c) __attribute__((always_inline)) {
+  auto process = [&](int half, const Pre& q, auto mode_c) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_c)::value;
-    constexpr bool FOLD = decltype(fold_c)::value;
 #pragma unroll
     for (int i = 0; i < EH; ++i) {
       const int it = half * EH + i;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       if constexpr (BNB) {
         // v holds the values as stored (rounded to T): exactly what BatchNorm backward will read back
         Vec16<T> xb;
-        xb.raw = make_uint4(q.x[i].x, q.x[i].y, q.x[i].z, q.x[i].w);
+        xb.raw = FOLD ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(q.x[i].x, q.x[i].y, q.x[i].z, q.x[i].w);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           float d = v.get(j);
@@ -552,22 +554,14 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
   };
   using std::integral_constant;
   if (bn_mode == 3) {
-    if (bn_fold) {
-      process(0, q0, integral_constant<int, 3>(), integral_constant<bool, true>());
-      process(1, q1, integral_constant<int, 3>(), integral_constant<bool, true>());
-    } else {
-      process(0, q0, integral_constant<int, 3>(), integral_constant<bool, false>());
-      process(1, q1, integral_constant<int, 3>(), integral_constant<bool, false>());
-    }
+    process(0, q0, integral_constant<int, 3>());
+    process(1, q1, integral_constant<int, 3>());
   } else if (bn_mode == 2) {
-    process(0, q0, integral_constant<int, 2>(), integral_constant<bool, false>());
-    process(1, q1, integral_constant<int, 2>(), integral_constant<bool, false>());
-  } else if (bn_fold) {
-    process(0, q0, integral_constant<int, 0>(), integral_constant<bool, true>());
-    process(1, q1, integral_constant<int, 0>(), integral_constant<bool, true>());
+    process(0, q0, integral_constant<int, 2>());
+    process(1, q1, integral_constant<int, 2>());
   } else {
-    process(0, q0, integral_constant<int, 0>(), integral_constant<bool, false>());
-    process(1, q1, integral_constant<int, 0>(), integral_constant<bool, false>());
+    process(0, q0, integral_constant<int, 0>());
+    process(1, q1, integral_constant<int, 0>());
   }
 #pragma unroll
   for (int j = 0; j < VEC / 2; ++j) {
@@ -644,7 +638,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 }
 
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false, bool AXF = false, bool CAT = false>
+          bool BIAS = false, bool AXF = false, bool CAT = false, bool FOLD = false>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
@@ -655,7 +649,7 @@ void launch_lean(const IgemmParams& p, hipStream_t stream) {
   if (AXF) lds = 2 * stage_bytes + 8 * p.Cred;            // (scale, shift) table behind both stages
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF, CAT>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF, CAT, FOLD>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -675,7 +669,7 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
     return;
   }
   if (p.A2 != nullptr) {               // two operands back to back + bias ("bn fold" data gradient), plain or with the reduction
-    if (bnb) launch_lean<T, BN, BKB, MINB, PF, false, false, true, false, 0, true, false, true>(p, stream);
+    if (bnb) launch_lean<T, BN, BKB, (BN == 128 && BKB == 64) ? 4 : MINB, PF, false, false, true, false, 0, true, false, true>(p, stream);
     else launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true, false, true>(p, stream);
     return;
   }
@@ -702,8 +696,17 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
       }
     }
 #endif
-    if (racc) launch_lean<T, BN, BKB, MINB, PF, false, true, true, false>(p, stream);
-    else launch_lean<T, BN, BKB, MINB, PF, false, false, true, false>(p, stream);
+    // (register budget of 4 workgroups per CU where the tile leaves the LDS for them: 128 x 128 tiles with 64-byte K
+    // tiles; the fold variants fit it, the others are 1-2 registers over without the bound)
+    constexpr int MB = (BN == 128 && BKB == 64) ? 4 : MINB;
+    if (p.flags & kIgemmBnFold) {
+      if (racc) launch_lean<T, BN, BKB, MB, PF, false, true, true, false, 0, false, false, false, true>(p, stream);
+      else launch_lean<T, BN, BKB, MB, PF, false, false, true, false, 0, false, false, false, true>(p, stream);
+    } else if (racc) {
+      launch_lean<T, BN, BKB, MINB, PF, false, true, true, false>(p, stream);
+    } else {
+      launch_lean<T, BN, BKB, MB, PF, false, false, true, false>(p, stream);
+    }
   } else if (stats) {
     launch_lean<T, BN, BKB, MINB, PF, true, false, false, false>(p, stream);
   } else if (racc) {
@@ -773,7 +776,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;
   // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
   // from the full BN output (1) stays with the general kernel
-  if ((p.flags & kIgemmBnFold) && (!bnb || !(p.bn_relu == 0 || p.bn_relu == 3))) return false;
+  if ((p.flags & kIgemmBnFold) && (!bnb || cat || !(p.bn_relu == 0 || p.bn_relu == 3))) return false;
   if (bnb && (p.stats == nullptr || p.bn_x == nullptr || p.bn_coef == nullptr || p.ldc != p.N ||
               !(p.bn_relu == 0 || p.bn_relu == 2 || p.bn_relu == 6 || (p.bn_relu == 3 && p.bn_z != nullptr))))
     return false;

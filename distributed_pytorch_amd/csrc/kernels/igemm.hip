@@ -130,6 +130,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       pbits[i] = p.bn_relu == 3 ? reinterpret_cast<const uint8_t*>(p.bn_z)[goff / 16] : 0u;
     }
   };
+  // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column, requested AHEAD of the
+  // rows' extra operands -- vmcnt retires in order, behind them they would make the first row wait for the last
+  // request (profiles/r3/lean_epilogue_vmcnt.md)
+  float bmu[VECO], bis[VECO], bsc[VECO], bsh[VECO];
+#pragma unroll
+  for (int j = 0; j < VECO; ++j) bmu[j] = bis[j] = bsc[j] = bsh[j] = 0.f;
+  if constexpr (BNB) {
+    if (!bn_fold) {
+#pragma unroll
+      for (int j = 0; j < VECO; ++j) {
+        // coef[4][stats_ld]: stats_ld = all channels of the BN (== N for a dense launch)
+        const long c = gofs + (ncol + j < p.N ? ncol + j : 0);
+        bmu[j] = p.bn_coef[c];
+        bis[j] = p.bn_coef[p.stats_ld + c];
+        bsc[j] = p.bn_coef[2 * (long)p.stats_ld + c];
+        bsh[j] = p.bn_coef[3 * (long)p.stats_ld + c];
+      }
+    }
+  }
   constexpr int E_HALF = E_IT > 1 ? E_IT / 2 : 1;
   if constexpr (BNB || XM) bnb_request(0, E_HALF);
 #pragma unroll
@@ -190,20 +209,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     }
   }
   char* __restrict__ Cg = reinterpret_cast<char*>(p.C) + gofs * sizeof(TOut);
-  // fused BatchNorm-backward reduction: per-channel constants of this thread's chunk column (the extra operands
-  // of every row were requested above)
-  float bmu[VECO], bis[VECO], bsc[VECO], bsh[VECO];
-  if constexpr (BNB) {
-#pragma unroll
-    for (int j = 0; j < VECO; ++j) {
-      // coef[4][stats_ld]: stats_ld = all channels of the BN (== N for a dense launch)
-      const long c = gofs + (ncol + j < p.N ? ncol + j : 0);
-      bmu[j] = p.bn_coef[c];
-      bis[j] = p.bn_coef[p.stats_ld + c];
-      bsc[j] = p.bn_coef[2 * (long)p.stats_ld + c];
-      bsh[j] = p.bn_coef[3 * (long)p.stats_ld + c];
-    }
-  }
 #pragma unroll
   for (int i = 0; i < E_IT; ++i) {
     const int row = (tid + i * 256) / CE;
