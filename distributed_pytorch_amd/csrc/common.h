@@ -95,6 +95,44 @@ __device__ __forceinline__ uint32_t bn_relu_pair_bf16(uint32_t w, f32x2_t sc, f3
   return r;
 }
 
+// ---- packed bf16 pair arithmetic for the streaming epilogues (v_pk_add_f32 / v_pk_fma_f32 / v_cvt_pk_bf16_f32): the
+// epilogue of a fused accumulate + BN-backward launch was VALU bound at ~22 instructions per element when every element
+// went through scalar get / select / set (bench/experiments/lean_racc_ablate.py); pairs take ~8.
+__device__ __forceinline__ f32x2_t unpack_bf16x2(uint32_t w) {
+  f32x2_t x;
+  x.x = __uint_as_float(w << 16);
+  x.y = __uint_as_float(w & 0xffff0000u);
+  return x;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2_t y) {
+  const bf16x2_t p = __builtin_convertvector(y, bf16x2_t);
+  uint32_t r;
+  __builtin_memcpy(&r, &p, 4);
+  return r;
+}
+// bits 2j, 2j+1 of a mask byte -> an AND mask for the bf16 pair j (low half = element 2j)
+__device__ __forceinline__ uint32_t pair_mask(uint32_t bits, int j) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * j, 1);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * j + 1, 1);
+  return (lo & 0x0000ffffu) | (hi & 0xffff0000u);        // v_bfi_b32
+}
+
+// (int16 view of a bf16 pair) > 0 per half -> AND mask 0xffff / 0: +0, -0, negatives and NaNs with the sign bit give 0
+__device__ __forceinline__ uint32_t pair_positive_mask(uint32_t w) {
+  s16x2_t v;
+  __builtin_memcpy(&v, &w, 4);
+  const s16x2_t zero = {0, 0}, one = {1, 1};
+  v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), one);      // 1 where > 0
+  typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+  u16x2_t u;
+  __builtin_memcpy(&u, &v, 4);
+  const u16x2_t ff = {0xffff, 0xffff};
+  u = u * ff;                                                                   // v_pk_mul_lo_u16
+  uint32_t r;
+  __builtin_memcpy(&r, &u, 4);
+  return r;
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 bn_relu_chunk(const uint4& raw, const float (&sc)[16 / sizeof(T)],
                                                const float (&sh)[16 / sizeof(T)]) {

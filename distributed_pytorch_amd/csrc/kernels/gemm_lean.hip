@@ -52,28 +52,6 @@ template <> struct LeanMma<f16_t> {
   }
 };
 
-// ---- packed bf16 pair arithmetic for the streaming epilogues (v_pk_add_f32 / v_pk_fma_f32 / v_cvt_pk_bf16_f32): the
-// epilogue of a fused accumulate + BN-backward launch was VALU bound at ~22 instructions per element when every element
-// went through scalar get / select / set (bench/experiments/lean_racc_ablate.py); pairs take ~8.
-__device__ __forceinline__ f32x2_t unpack_bf16x2(uint32_t w) {
-  f32x2_t x;
-  x.x = __uint_as_float(w << 16);
-  x.y = __uint_as_float(w & 0xffff0000u);
-  return x;
-}
-__device__ __forceinline__ uint32_t pack_bf16x2(f32x2_t y) {
-  const bf16x2_t p = __builtin_convertvector(y, bf16x2_t);
-  uint32_t r;
-  __builtin_memcpy(&r, &p, 4);
-  return r;
-}
-// bits 2j, 2j+1 of a mask byte -> an AND mask for the bf16 pair j (low half = element 2j)
-__device__ __forceinline__ uint32_t pair_mask(uint32_t bits, int j) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * j, 1);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * j + 1, 1);
-  return (lo & 0x0000ffffu) | (hi & 0xffff0000u);        // v_bfi_b32
-}
-
 int g_lean_abl = 0;     // debug ablation of the plain variant (scratch/lean_ablate.py)
 int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 force 128-byte K tiles
 

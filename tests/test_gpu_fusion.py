@@ -53,15 +53,21 @@ def test_bn_relu_apply_on_load(case, dtype):
     b0 = torch.randn(Cin, device=DEV) * 0.3
     w0 = (torch.randn(Cout, Cin, k, k, device=DEV) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
     res = []
-    for fused in (True, False):
-        x = x0.clone().requires_grad_(True)
-        g, b, w = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
-        y, deferred = _chain(x, g, b, w, s, p, fused)
-        assert deferred == fused
-        torch.manual_seed(12)
-        gy = torch.randn_like(y.float()).to(dtype)
-        y.backward(gy)
-        res.append((y.detach(), x.grad, g.grad, b.grad, w.grad, gy))
+    # bit-identity is a statement about ONE weight-gradient kernel with and without the transform on load: the
+    # filter-row kernel (no apply-on-load variant) would take the unfused 64-channel 3x3 case and sum in another order
+    hip_ops.C().wgrad_row3_set_mode(0)
+    try:
+        for fused in (True, False):
+            x = x0.clone().requires_grad_(True)
+            g, b, w = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y, deferred = _chain(x, g, b, w, s, p, fused)
+            assert deferred == fused
+            torch.manual_seed(12)
+            gy = torch.randn_like(y.float()).to(dtype)
+            y.backward(gy)
+            res.append((y.detach(), x.grad, g.grad, b.grad, w.grad, gy))
+    finally:
+        hip_ops.C().wgrad_row3_set_mode(-1)
     (yf, dxf, dgf, dbf, dwf, gy), (yu, dxu, dgu, dbu, dwu, _) = res
     assert torch.equal(yf, yu), "forward differs from the unfused kernels"
     assert torch.equal(dwf, dwu), "weight gradient differs from the unfused kernels"
