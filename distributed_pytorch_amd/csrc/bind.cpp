@@ -41,6 +41,7 @@ PYBIND11_MODULE(_C, m) {
           p.stats_ld = stats_ld;
           p.bn_x = ptr<const void>(bn_x);
           p.bn_z = ptr<const void>(bn_z);
+          if (flags & kIgemmReluMask) p.relu_mask = ptr<uint8_t>(bn_z);      // (the slot doubles as the mask OUTPUT)
           p.bn_coef = ptr<const float>(bn_coef);
           p.bn_relu = bn_relu;
           p.A = ptr<const void>(A);
@@ -79,6 +80,7 @@ PYBIND11_MODULE(_C, m) {
   m.def("igemm_set_tail_min", &igemm_set_tail_min);
   m.def("igemm_set_lean", &igemm_set_lean);
   m.attr("IGEMM_BN_FOLD") = (int)kIgemmBnFold;
+  m.attr("IGEMM_RELU_MASK") = (int)kIgemmReluMask;
   m.def("bnfold_coeffs", [](uintptr_t raw, uintptr_t w, int ldw, uintptr_t dbeta_sum, uintptr_t mean, uintptr_t invstd,
                             uintptr_t gamma, double count, int N, int C, uintptr_t dgamma_out, float beta_g,
                             uintptr_t dbeta_out, float beta_b, uintptr_t coef, uintptr_t wt_scaled, int ldwt, uintptr_t ax, int dtype,
@@ -86,6 +88,13 @@ PYBIND11_MODULE(_C, m) {
     bnfold_coeffs_launch(ptr<const float>(raw), ptr<const void>(w), ldw, ptr<const float>(dbeta_sum), ptr<const float>(mean),
                          ptr<const float>(invstd), ptr<const float>(gamma), count, N, C, ptr<float>(dgamma_out), beta_g,
                          ptr<float>(dbeta_out), beta_b, ptr<float>(coef), ptr<void>(wt_scaled), ldwt, ptr<void>(ax), dtype, st(s));
+  });
+  m.def("bnfold_fwd", [](uintptr_t t, uintptr_t w, uintptr_t cs, double count, uintptr_t gamma, uintptr_t beta, float eps,
+                         float momentum, uintptr_t rm, uintptr_t rv, uintptr_t nbt, uintptr_t coef, uintptr_t wsc, int N, int C,
+                         int dtype, uintptr_t s) {
+    bnfold_fwd_launch(ptr<const float>(t), ptr<const float>(w), ptr<const float>(cs), count, ptr<const float>(gamma),
+                      ptr<const float>(beta), eps, momentum, ptr<float>(rm), ptr<float>(rv), ptr<long>(nbt), ptr<float>(coef),
+                      ptr<void>(wsc), N, C, dtype, st(s));
   });
   m.def("bnfold_wgrad", [](uintptr_t raw, uintptr_t wg, uintptr_t coef, uintptr_t cs, uintptr_t out, int N, int C, float beta,
                            uintptr_t s) {

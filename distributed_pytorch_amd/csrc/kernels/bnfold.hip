@@ -73,6 +73,59 @@ __global__ __launch_bounds__(256) void bnfold_wgrad_kernel(const float* __restri
   }
 }
 
+// ---- forward: BatchNorm statistics of z = a W^T WITHOUT z ------------------------------------------------------------
+// mean_z[n] = w_n . colsum(a) / M and E[z^2][n] = w_n^T (a^T a) w_n / M: with t = W (a^T a) (an fp32 GEMM on the small
+// matrices) both are row dot products.  The convolution then runs with the scaled weights scale o W and the shift as its
+// bias and applies residual + ReLU in its epilogue: the pre-BatchNorm tensor z is never written (hip_ops._ConvBnResReluFn).
+// Sums in double: E[z^2] - mean^2 cancels when |mean| >> std.
+template <typename T>
+__global__ __launch_bounds__(256) void bnfold_fwd_kernel(const float* __restrict__ t, const float* __restrict__ w,
+                                                        const float* __restrict__ cs, double count,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, float momentum, float* running_mean, float* running_var,
+                                                        long* nbt, float* __restrict__ coef, T* __restrict__ wsc, int N, int C) {
+  __shared__ double red[2][256];
+  __shared__ float sc_s;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  double sm = 0.0, sq = 0.0;
+  for (int c = tid; c < C; c += 256) {
+    const double wf = (double)w[(size_t)n * C + c];
+    sm += wf * (double)cs[c];
+    sq += wf * (double)t[(size_t)n * C + c];
+  }
+  red[0][tid] = sm;
+  red[1][tid] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] += red[0][tid + o];
+      red[1][tid] += red[1][tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = red[0][0] / count;
+    double var = red[1][0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+    coef[n] = (float)mean;
+    coef[N + n] = is;
+    coef[2 * N + n] = g * is;
+    coef[3 * N + n] = b - (float)mean * g * is;
+    sc_s = g * is;
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+      running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+    }
+    if (n == 0 && nbt != nullptr) *nbt += 1;
+  }
+  __syncthreads();
+  const float sc = sc_s;
+  for (int c = tid; c < C; c += 256) wsc[(size_t)n * C + c] = from_float<T>(sc * w[(size_t)n * C + c]);
+}
+
 }  // namespace
 
 void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float* dbeta_sum, const float* mean,
@@ -100,6 +153,16 @@ void bnfold_wgrad_launch(const float* raw, const float* wg, const float* coef, c
   const long total = (long)N * C;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(bnfold_wgrad_kernel, dim3(blocks), dim3(256), 0, s, raw, wg, coef, cs, out, N, C, beta);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void bnfold_fwd_launch(const float* t, const float* w, const float* cs, double count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* coef, void* wsc,
+                       int N, int C, int dtype, hipStream_t s) {
+  if (N <= 0 || C <= 0) return;
+  if (dtype == kF32) throw std::invalid_argument("bnfold_fwd: 16-bit activations");
+  DPA_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bnfold_fwd_kernel<T>), dim3(N), dim3(256), 0, s, t, w, cs, count, gamma, beta,
+                                               eps, momentum, running_mean, running_var, nbt, coef, (T*)wsc, N, C));
   DPA_CHECK_HIP(hipGetLastError());
 }
 

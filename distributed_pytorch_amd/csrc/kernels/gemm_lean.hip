@@ -59,13 +59,15 @@ int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 fo
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
 // CAT: the reduction runs over two gathered operands back to back (IgemmParams::A2): when the K tiles of the first are
 // used up the staging base and the per-row offsets switch to the second, nothing else in the loop changes.
+// RELUM (kIgemmReluMask): C = relu(acc + bias + R), ReLU bit mask written next to it.
 // FOLD: the BNB launch is a kIgemmBnFold one (masked store, sum dz_m only): the BN input and the coefficients are never
 // requested -- compiled apart because their registers decide between 3 and 4 workgroups per CU.
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false, bool AXF = false, bool CAT = false, bool FOLD = false>
+          bool BIAS = false, bool AXF = false, bool CAT = false, bool FOLD = false, bool RELUM = false>
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   static_assert(!FOLD || BNB, "FOLD is a BNB launch");
+  static_assert(!RELUM || (BIAS && RACC && !BNB && !STATS), "RELUM: relu(acc + bias + R) with the ReLU bit mask as a second output");
   constexpr int BM = 128;
   constexpr int VEC = 8;
   constexpr int BK = BKB / 2;
@@ -460,6 +462,37 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
       const int row = er0 + it * RPE;
       if (row >= rows) continue;
       char* dst = Cg + (coff0 + (uint32_t)it * cstep);
+      if constexpr (RELUM) {
+        uint32_t bits = 0u;
+        if constexpr (TypeInfo<T>::kCode == kBF16) {
+          const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(se + row * LDE + ce * 16);
+          u32x4_t o;
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            const uint32_t rm = q.r[i][pr] & pair_mask(q.rbits[i], pr);
+            const uint32_t w = pack_bf16x2(unpack_bf16x2(vv[pr]) + unpack_bf16x2(rm));
+            const uint32_t m = pair_positive_mask(w);
+            o[pr] = w & m;
+            bits |= ((m & 1u) | ((m >> 15) & 2u)) << (2 * pr);
+          }
+          if (nt_store) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst));
+          else *reinterpret_cast<u32x4_t*>(dst) = o;
+        } else {
+          Vec16<T> v, r;
+          v.load(se + row * LDE + ce * 16);
+          r.raw = make_uint4(q.r[i].x, q.r[i].y, q.r[i].z, q.r[i].w);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float f = v.get(j) + (((q.rbits[i] >> j) & 1u) ? r.get(j) : 0.f);
+            v.set(j, fmaxf(f, 0.f));
+            bits |= (v.get(j) > 0.f ? 1u : 0u) << j;
+          }
+          if (nt_store) v.store_nt(dst);
+          else v.store(dst);
+        }
+        p.relu_mask[(cbase + coff0 + (size_t)it * cstep) >> 4] = (uint8_t)bits;
+        continue;
+      }
       if constexpr (BNB && !STATS && MODE != 2 && TypeInfo<T>::kCode == kBF16) {
         // bf16, mask absent (0: xbits = 0xff) or as bits (3): whole pairs at a time
         const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(se + row * LDE + ce * 16);
@@ -616,7 +649,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
 }
 
 template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, bool BNB, bool STRIDED, int ABL = 0,
-          bool BIAS = false, bool AXF = false, bool CAT = false, bool FOLD = false>
+          bool BIAS = false, bool AXF = false, bool CAT = false, bool FOLD = false, bool RELUM = false>
 void launch_lean(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDR = BKB + 16;
   constexpr int stage_bytes = (128 + BN) * LDR;
@@ -627,7 +660,7 @@ void launch_lean(const IgemmParams& p, hipStream_t stream) {
   if (AXF) lds = 2 * stage_bytes + 8 * p.Cred;            // (scale, shift) table behind both stages
   if (lds < epi_bytes) lds = epi_bytes;
   if (lds < red_bytes) lds = red_bytes;
-  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF, CAT, FOLD>;
+  auto kern = gemm_lean_kernel<T, BN, BKB, MINB, PF, STATS, RACC, BNB, STRIDED, ABL, BIAS, AXF, CAT, FOLD, RELUM>;
   static bool attr_done = false;
   if (!attr_done && max_lds > 64 * 1024) {
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -649,6 +682,10 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
   if (p.A2 != nullptr) {               // two operands back to back + bias ("bn fold" data gradient), plain or with the reduction
     if (bnb) launch_lean<T, BN, BKB, (BN == 128 && BKB == 64) ? 4 : MINB, PF, false, false, true, false, 0, true, false, true>(p, stream);
     else launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true, false, true>(p, stream);
+    return;
+  }
+  if (p.flags & kIgemmReluMask) {      // bottleneck tail: relu(acc + shift + identity) + bit mask
+    launch_lean<T, BN, BKB, MINB, PF, false, true, false, false, 0, true, false, false, false, true>(p, stream);
     return;
   }
   if (p.bias != nullptr) {             // Linear forward (gemm_lean_try admits a bias only on the plain variant)
@@ -750,7 +787,11 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
   if (cat && (p.bias == nullptr || p.R != nullptr || (p.stats != nullptr && !bnb) || p.Cred2 <= 0 || p.Cred2 % 32 ||
               p.lda2 % 8 || (p.B2 != nullptr && p.ldb2 % 8) || (p.flags & (kIgemmAxf | kIgemmRStrided))))
     return false;
-  if (!cat && p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;
+  const bool relum = p.flags & kIgemmReluMask;
+  if (relum && (cat || bnb || p.bias == nullptr || p.R == nullptr || p.relu_mask == nullptr || p.stats != nullptr ||
+                p.ldc != p.N || (p.flags & (kIgemmAxf | kIgemmRStrided | kIgemmRelu))))
+    return false;
+  if (!cat && !relum && p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;
   if (p.stats != nullptr && ((p.R != nullptr && !bnb) || (p.stats_ld != 0 && p.stats_ld != p.N))) return false;
   // fused BN-backward reduction: dense rows; the ReLU mask as bits (3), recomputed (2) or absent (0) -- a mask read
   // from the full BN output (1) stays with the general kernel

@@ -1293,12 +1293,15 @@ void igemm_launch(const IgemmParams& p_in, int dtype, int out_dtype, hipStream_t
     p.bn_z = nullptr;
   }
   t_xmask_done = false;
-  if (g_force_cfg < 0 && p.A2 == nullptr && conv8_try(p, dtype, out_dtype, stream)) return;
-  if (!(p.flags & kIgemmXMask) && (p.flags & kIgemmDense1) && (g_force_cfg < 0 || p.A2 != nullptr) &&
+  const bool lean_only = p.A2 != nullptr || (p.flags & kIgemmReluMask);
+  if (g_force_cfg < 0 && !lean_only && conv8_try(p, dtype, out_dtype, stream)) return;
+  if (!(p.flags & kIgemmXMask) && (p.flags & kIgemmDense1) && (g_force_cfg < 0 || lean_only) &&
       gemm_lean_try(p, dtype, out_dtype, stream)) {
     DPA_CHECK_HIP(hipGetLastError());
     return;
   }
+  if (p.flags & kIgemmReluMask)
+    throw std::invalid_argument("igemm: relu(acc + bias + R) with a bit-mask output is only implemented by the lean GEMM (dense 1x1, 16-bit)");
   if (p.flags & kIgemmRStrided)
     throw std::invalid_argument("igemm: a compact strided accumulate is only implemented by the lean GEMM");
   if (p.A2 != nullptr)

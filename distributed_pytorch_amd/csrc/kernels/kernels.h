@@ -14,6 +14,9 @@ namespace dpa {
 // kIgemmRStrided (lean GEMM only): R is compact [NB, OHF, OWF, ldc]; output pixel (y, x) adds R[y / OSY][x / OSX] when
 // y % OSY == 0 and x % OSX == 0 (powers of two) -- the data gradient of a strided 1x1 branch, never scattered into a
 // zero-filled full-size tensor.
+// kIgemmReluMask (lean GEMM only, with a bias and R): C = relu(acc + bias + R), and one byte per 16-byte chunk of C goes
+// to relu_mask (bit j = element j > 0): the tail of a bottleneck -- scaled 1x1 convolution + BN shift + identity + ReLU
+// -- in the convolution's epilogue (hip_ops._ConvBnResReluFn).
 // kIgemmBnFold (with kIgemmBnBwd, bn_relu 0 or 3): the BatchNorm's producer is a 1x1 convolution whose backward folds the
 // BatchNorm backward into its own GEMMs (hip_ops._ConvFn, "bn fold"): the gradient is STORED through the ReLU mask, the
 // slab receives only sum dz_m (second row zeros) and bn_x is never read -- sum dz_m * xhat follows from the weight gradient.
@@ -21,7 +24,8 @@ namespace dpa {
 // so every output pixel (oy, ox) reads input pixel (oy * SY, ox * SX): such launches may run the lean GEMM
 // (gemm_lean.hip: no tap bookkeeping, no padding masks).
 enum IgemmFlags : int { kIgemmRelu = 1, kIgemmScatter = 2, kIgemmBnBwd = 4, kIgemmRow3 = 8, kIgemmNtStore = 16,
-                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128, kIgemmXMask = 256, kIgemmBnFold = 512 };
+                        kIgemmAxf = 32, kIgemmDense1 = 64, kIgemmRStrided = 128, kIgemmXMask = 256, kIgemmBnFold = 512,
+                        kIgemmReluMask = 1024 };
 
 struct IgemmParams {
   const void* A;       // gathered operand: NHWC activations [NB, IH, IW, lda]
@@ -45,6 +49,7 @@ struct IgemmParams {
   // second gathered operand (lean GEMM only, dense 1x1): the reduction continues over Cred2 channels of A2 (rows of lda2
   // elements, same pixels), against columns Cred .. Cred + Cred2 - 1 of B -- C = [A | A2] [B1 | B2]^T in one launch
   // (the "bn fold" data gradient: dy_m (A o W) + a (W^T diag(B) W))
+  uint8_t* relu_mask = nullptr;      // kIgemmReluMask: the ReLU bit mask of C (output)
   const void* A2 = nullptr;
   int lda2 = 0, Cred2 = 0;
   const void* B2 = nullptr;         // optional: the second range's weights live in their own matrix [N][ldb2] (else: in B)
@@ -205,6 +210,11 @@ void bnfold_coeffs_launch(const float* raw, const void* w, int ldw, const float*
                           float beta_g, float* dbeta_out, float beta_b, float* coef, void* wt_scaled, int ldwt, void* bw, int dtype,
                           hipStream_t s);
 // out[n][c] = beta * out + A[n] raw[n][c] + B[n] wg[n][c] + K[n] cs[c]
+// forward statistics of z = a W^T from t = W (a^T a) and cs = colsum(a) (no pass over z): coef[4][N] = mean, invstd, scale, shift;
+// wsc = scale o W in `dtype`; running statistics updated like bn_fold_finalize
+void bnfold_fwd_launch(const float* t, const float* w, const float* cs, double count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* coef, void* wsc,
+                       int N, int C, int dtype, hipStream_t s);
 void bnfold_wgrad_launch(const float* raw, const float* wg, const float* coef, const float* cs, float* out, int N, int C,
                          float beta, hipStream_t s);
 

@@ -304,6 +304,13 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip
     per-channel sum/sumsq partials that BN consumes, so the conv output is not
     re-read for statistics.  ``skip=True`` -> ``(out, x_alias)`` (see ``F.conv2d``)."""
     fuse = F._on_gpu(x) and bn.training and bn.process_group is None
+    if fuse and residual is not None and relu is True and act is None and not skip and not defer \
+            and conv.groups == 1 and conv.bias is None and conv.needs_input_grad:
+        # bottleneck tail: statistics from the Gram matrix of x, BN + residual + ReLU in the convolution's epilogue
+        y = F._hip().conv_bn_res_relu(x, conv.weight, conv.stride, conv.padding, bn.weight, bn.bias, bn.running_mean,
+                                      bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, residual)
+        if y is not None:
+            return y
     out = conv(x, want_stats=fuse, skip=skip)
     alias = None
     if skip:

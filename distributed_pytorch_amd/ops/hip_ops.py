@@ -16,6 +16,7 @@ import math
 import functools
 import collections
 import os
+import types
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -258,7 +259,7 @@ def _conv_out(i, k, s, p):
 
 def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH, IW, SY, SX, OH, OW,
            scatter=None, relu=False, dtype=None, out_dtype=None, accum=None, bnred=None, groups=None, row3=False,
-           accum_mask=None, axf=None, rstride=None, xmask=None, cat=None):
+           accum_mask=None, axf=None, rstride=None, xmask=None, cat=None, relu_mask=None):
     """``cat``: (A2, lda2, Cred2[, B2, ldb2]) -- the reduction continues over a second gathered operand against the next
     Cred2 columns of B, or against B2 (lean GEMM, dense 1x1; needs a bias).
     ``xmask``: a ReLU output with the layout of the result; result elements where it is <= 0 are stored as 0.
@@ -284,6 +285,9 @@ def _igemm(A, B, Cout_t, bias, stats, taps, M, N, Cred, ntaps, lda, ldb, ldc, IH
     if xmask is not None:
         flags |= C().IGEMM_XMASK
         bn_x = xmask.data_ptr()
+    if relu_mask is not None:           # C = relu(acc + bias + accum), ReLU bit mask written to `relu_mask` (lean GEMM)
+        flags |= C().IGEMM_RELU_MASK
+        bn_z = relu_mask.data_ptr()
     OHF = OWF = OSY = OSX = OY0 = OX0 = 0
     if scatter is not None:
         flags |= C().IGEMM_SCATTER
@@ -408,9 +412,11 @@ def _grad_into(param, fill):
     param.grad = g if param.grad is None else param.grad + g
 
 
-def _conv_bn_fold_backward(ctx, fent):
+def _conv_bn_fold_backward(ctx, fent, pre=None):
     """Backward of (1x1 convolution -> training BatchNorm [+ residual + ReLU]) without the BatchNorm-backward apply pass:
-    see csrc/kernels/bnfold.hip for the algebra.  `fent` comes from _BNFn.backward, `ctx` is the convolution's."""
+    see csrc/kernels/bnfold.hip for the algebra.  `fent` comes from _BNFn.backward, `ctx` is the convolution's.
+    ``pre`` = (gram, colsum(a), W gram) kept from a forward pass that took the BatchNorm statistics from them
+    (_ConvBnResReluFn); ``part`` may then be None (no producer reduced sum dy_m: it is reduced here)."""
     _, dy, part, coef, gamma, beta_p, count, _ = fent
     a, weight, _ = ctx.saved_tensors
     full_shape = tuple(a.shape)
@@ -424,13 +430,20 @@ def _conv_bn_fold_backward(ctx, fent):
     dev, dt, st = a.device, a.dtype, _stream()
     bn_fold_counts["folded"] += 1
     # ---- reductions over the pixels: raw = dy_m^T a, gram = a^T a, cs = colsum(a), dbeta = colsum(dy_m) (producer's slab)
-    rg = _wgrad_raw(dy, a, M, N, Cx, IH, IW, gram=True)     # one launch: a is staged once for both products
-    raw, gram = rg[:N], rg[N:]
-    cs = _colsum(a.view(M, Cx))
-    dbeta_sum = torch.empty(N, dtype=torch.float32, device=dev)
-    scratch = torch.empty(N, dtype=torch.float32, device=dev)
-    partf = _fold(part, N)              # (thousands of 128-row parts: folded by many workgroups first)
-    C().bn_bwd_finalize(partf.data_ptr(), partf.shape[0], N, scratch.data_ptr(), dbeta_sum.data_ptr(), st)
+    if pre is None:
+        rg = _wgrad_raw(dy, a, M, N, Cx, IH, IW, gram=True)     # one launch: a is staged once for both products
+        raw, gram = rg[:N], rg[N:]
+        cs = _colsum(a.view(M, Cx))
+    else:
+        raw = _wgrad_raw(dy, a, M, N, Cx, IH, IW)
+        gram, cs = pre[0], pre[1]
+    if part is None:
+        dbeta_sum = _colsum(dy.view(M, N))
+    else:
+        dbeta_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        scratch = torch.empty(N, dtype=torch.float32, device=dev)
+        partf = _fold(part, N)              # (thousands of 128-row parts: folded by many workgroups first)
+        C().bn_bwd_finalize(partf.data_ptr(), partf.shape[0], N, scratch.data_ptr(), dbeta_sum.data_ptr(), st)
     # ---- BatchNorm coefficients (A, B, K), dgamma / dbeta, and the scaled weight operands
     wlp = conv_weight(weight, dt, Cx)                                 # [N][Cx] as the forward pass used it
     abk = torch.empty((3, N), dtype=torch.float32, device=dev)
@@ -495,10 +508,13 @@ def _conv_bn_fold_backward(ctx, fent):
                 dx = _expand_compact((None, dx, (sh, sw), _generation, full_shape))
     # ---- weight gradient: A o raw + B o (W gram) + K (x) cs, W gram in fp32 (the terms cancel)
     if ctx.needs_input_grad[1]:
-        wg = torch.empty((N, Cx), dtype=torch.float32, device=dev)
-        w32 = weight.detach()
-        _igemm(w32, gram, wg, None, None, one, N, Cx, Cx, 1, Cx, Cx, Cx, 1, N, 1, 1, 1, N, dtype=torch.float32,
-               out_dtype=torch.float32)
+        if pre is not None:
+            wg = pre[2]
+        else:
+            wg = torch.empty((N, Cx), dtype=torch.float32, device=dev)
+            w32 = weight.detach()
+            _igemm(w32, gram, wg, None, None, one, N, Cx, Cx, 1, Cx, Cx, Cx, 1, N, 1, 1, 1, N, dtype=torch.float32,
+                   out_dtype=torch.float32)
 
         def fill_w(view, beta):
             C().bnfold_wgrad(raw.data_ptr(), wg.data_ptr(), abk.data_ptr(), cs.data_ptr(), view.data_ptr(), N, Cx,
@@ -506,6 +522,116 @@ def _conv_bn_fold_backward(ctx, fent):
 
         _grad_into(weight, fill_w)
     return dx, None, None, None, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# Tail of a bottleneck in ONE GEMM: out = relu(BN(a W^T) + identity) with the BatchNorm statistics taken from the Gram
+# matrix of a (csrc/kernels/bnfold.hip: bnfold_fwd) -- the pre-BatchNorm tensor is never written or read.  Backward is
+# the "bn fold" above with the Gram matrix, colsum(a) and W gram kept from forward.
+# ------------------------------------------------------------------------------------------
+_BN_FWD_FOLD = os.environ.get("DPA_BN_FWD_FOLD", "1") == "1"
+bn_fwd_fold_counts = {"fused": 0}
+
+
+class _ConvBnResReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, weight, gamma, beta, residual, running_mean, running_var, nbt, momentum, eps, bnsrc):
+        NB, IH, IW, Cx = a.shape
+        N = weight.shape[0]
+        M = NB * IH * IW
+        dev, dt, st = a.device, a.dtype, _stream()
+        one = _tap_table(dev, ((0, 0, 0),))
+        # ---- statistics of z = a W^T from a^T a and colsum(a)
+        gram = _wgrad_raw(a, a, M, Cx, Cx, IH, IW)
+        cs = _colsum(a.view(M, Cx))
+        w32 = weight.detach()               # [N, Cx, 1, 1]: N rows of Cx in either memory format
+        wg = torch.empty((N, Cx), dtype=torch.float32, device=dev)
+        _igemm(w32, gram, wg, None, None, one, N, Cx, Cx, 1, Cx, Cx, Cx, 1, N, 1, 1, 1, N, dtype=torch.float32,
+               out_dtype=torch.float32)
+        coef = torch.empty((4, N), dtype=torch.float32, device=dev)       # mean, invstd, scale, shift
+        wsc = torch.empty((N, Cx), dtype=dt, device=dev)                   # scale o W
+        g32, b32 = _f32(gamma.detach()), _f32(beta.detach())
+        C().bnfold_fwd(wg.data_ptr(), w32.data_ptr(), cs.data_ptr(), float(M), g32.data_ptr(), b32.data_ptr(), float(eps),
+                       float(momentum), _p(running_mean), _p(running_var), _p(nbt), coef.data_ptr(), wsc.data_ptr(), N, Cx,
+                       _dt(a), st)
+        # ---- out = relu(a (scale o W)^T + shift + identity), ReLU bit mask on the side
+        out = torch.empty((NB, IH, IW, N), dtype=dt, device=dev)
+        mask = torch.empty(M * N // _vec(dt), dtype=torch.uint8, device=dev)
+        _igemm(a, wsc, out, coef[3], None, one, M, N, Cx, 1, Cx, Cx, N, IH, IW, 1, 1, IH, IW, dtype=dt, out_dtype=dt,
+               accum=residual, relu_mask=mask)
+        bn_fwd_fold_counts["fused"] += 1
+        ctx.bnsrc = None
+        if bnsrc is not None:
+            bnsrc.uses += 1
+            if _FUSE_BN_BWD and bnsrc.x.shape == a.shape and bnsrc.x.dtype == a.dtype \
+                    and _FUSE_BN_BWD_MIN <= a.numel() * a.element_size() <= _FUSE_BN_BWD_MAX:
+                ctx.bnsrc = bnsrc
+        ctx.save_for_backward(a, weight, gamma, coef, mask, gram, cs, wg)
+        ctx.beta_ref = beta
+        ctx.count = float(M)
+        ctx.out_ptr = out.data_ptr()
+        ctx.set_materialize_grads(False)
+        _ConvBnResReluFn.last = _BnSrc(out, coef, 3, mask, True)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, weight, gamma, coef, mask, gram, cs, wg = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 11
+        part = None
+        fused = _pending_bnred.pop(dy.data_ptr(), None)
+        if fused is not None and len(fused) > 3 and fused[3] and fused[1] == ctx.out_ptr and fused[2] == dy._version \
+                and dy.is_contiguous():
+            part = fused[0]         # the consumer's data gradient stored dy THROUGH the mask and reduced sum dy_m
+        else:
+            ent = _pending_mask.pop(dy.data_ptr(), None)
+            dy = dy if dy.is_contiguous() else dy.contiguous()
+            if ent is not None and ent[1] == dy._version and ent[2] == _generation \
+                    and ent[0].numel() * _vec(dy.dtype) == dy.numel():
+                dy = apply_bit_mask(dy, ent[0])     # (a lazily masked gradient of some other branch)
+            dy = apply_bit_mask(dy, mask)
+        fent = (None, dy, part, coef, gamma, ctx.beta_ref, ctx.count, _generation)
+        fctx = types.SimpleNamespace(saved_tensors=(a, weight, None), geom=((1, 1), (0, 0), False, True, False),
+                                     bnsrc=ctx.bnsrc, compact=False,
+                                     needs_input_grad=(ctx.needs_input_grad[0], ctx.needs_input_grad[1]))
+        ctx.bnsrc = None
+        da = _conv_bn_fold_backward(fctx, fent, pre=(gram, cs, wg))[0]
+        dres = dy if ctx.needs_input_grad[4] else None
+        return da, None, None, None, dres, None, None, None, None, None, None
+
+
+_ConvBnResReluFn.last = None
+
+
+def conv_bn_res_relu(x, weight, stride, padding, gamma, beta, running_mean, running_var, nbt, momentum, eps, residual):
+    """``relu(batch_norm(conv1x1(x)) + residual)`` in training mode as one GEMM, or None when the launch is not one the
+    fused path takes (the caller then runs conv -> batch_norm)."""
+    if not (_BN_FWD_FOLD and residual is not None and momentum is not None and running_mean is not None):
+        return None
+    if getattr(x, "_dpa_deferred_coef", None) is not None and not getattr(x, "_dpa_deferred_relu", False):
+        return None
+    if getattr(residual, "_dpa_deferred_coef", None) is not None:
+        return None
+    if tuple(stride) != (1, 1) or not _bn_fold_eligible(x, weight, None, stride, padding, False, True, True, False):
+        return None
+    NB, IH, IW, Cx = x.shape
+    N = weight.shape[0]
+    if tuple(residual.shape) != (NB, IH, IW, N) or residual.dtype != x.dtype or not residual.is_contiguous():
+        return None
+    if not gamma.requires_grad or not beta.requires_grad or N % 128:
+        return None
+    grad_sink.note_use(weight, None)
+    grad_sink.note_use(gamma, beta)
+    if getattr(x, "_dpa_deferred_coef", None) is not None:
+        x = materialize(x)          # the GEMMs of both directions run on the normalised activation itself
+    x = x if x.is_contiguous() else x.contiguous()
+    out = _ConvBnResReluFn.apply(x, weight, gamma, beta, residual, running_mean, running_var, nbt, float(momentum),
+                                 float(eps), getattr(x, "_dpa_bn", None))
+    if _ConvBnResReluFn.last is not None and torch.is_grad_enabled():
+        out._dpa_bn = _ConvBnResReluFn.last     # the consuming convolution stores its data gradient through the mask
+    _ConvBnResReluFn.last = None
+    return out
 
 
 class _ConvFn(torch.autograd.Function):

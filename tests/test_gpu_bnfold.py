@@ -40,7 +40,7 @@ class Stack(torch.nn.Module):
         return x
 
 
-def _run(fold, planes, shape, seed=0, stride=0):
+def _run(fold, planes, shape, seed=0, stride=0, fwd=False):
     torch.manual_seed(seed)
     net = Stack(planes, stride=stride).to(DEV).train()
     for m in net.modules():           # non-trivial BN parameters
@@ -54,45 +54,29 @@ def _run(fold, planes, shape, seed=0, stride=0):
     x = (torch.randn(N, H, W, net.cin, device=DEV).relu() + 0.1).to(torch.bfloat16).requires_grad_(True)
     st = max(stride, 1)
     gy = torch.randn(N, (H + st - 1) // st, (W + st - 1) // st, planes * 4, device=DEV).to(torch.bfloat16)
-    old, old_mb = hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB
+    old, old_mb, old_fwd = hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB, hip_ops._BN_FWD_FOLD
     hip_ops._BN_FOLD = fold
+    hip_ops._BN_FWD_FOLD = fwd              # statistics from the Gram matrix, BN + residual + ReLU in the GEMM epilogue
     hip_ops._BN_FOLD_MIN_MB = 0.0           # (the default leaves tensors this small to the ordinary backward)
     hip_ops.bn_fold_counts["folded"] = 0
+    hip_ops.bn_fwd_fold_counts["fused"] = 0
     try:
         opt.zero_grad()
         y = net(x)
         y.backward(gy)
     finally:
-        hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB = old, old_mb
+        hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB, hip_ops._BN_FWD_FOLD = old, old_mb, old_fwd
     torch.cuda.synchronize()
     grads = {n: p.grad.detach().float().clone() for n, p in net.named_parameters()}
     return net, x, gy, y.detach().float(), x.grad.detach().float(), grads, hip_ops.bn_fold_counts["folded"]
 
 
-@pytest.mark.parametrize("planes,shape,stride", [(64, (4, 14, 14), 0), (128, (3, 9, 11), 0), (64, (4, 14, 14), 1),
-                                                 (64, (3, 14, 18), 2)])
-def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, shape, stride):
-    net, x, gy, y1, dx1, g1, folded = _run(True, planes, shape, stride=stride)
-    _, _, _, y0, dx0, g0, none = _run(False, planes, shape, stride=stride)
-    # blocks 0 and 1: their bn3 receives a fused, pre-masked gradient; with a downsample branch its BatchNorm folds too
-    assert folded == (3 if stride else 2) and none == 0
-    assert torch.equal(y1, y0)
-    # fp32 reference with the SAME (bf16-rounded) weights and input
-    def ref_block(blk, t):
-        def cbr(t, conv, bn, relu, res=None):
-            w = conv.weight.detach().to(torch.bfloat16).float()
-            z = TF.conv2d(t, w, None, conv.stride, conv.padding)
-            o = TF.batch_norm(z, None, None, bn.weight.detach().float(), bn.bias.detach().float(), True, 0.0, bn.eps)
-            if res is not None:
-                o = o + res
-            return TF.relu(o) if relu else o
-        o = cbr(t, blk.conv1, blk.bn1, True)
-        o = cbr(o, blk.conv2, blk.bn2, True)
-        return cbr(o, blk.conv3, blk.bn3, True, t)
+def _reference(net, x, gy):
+    """fp32 PyTorch reference of the stack with the SAME (bf16-rounded) weights and input: (y, input gradient NCHW,
+    parameter gradients by name)."""
     params = {n: p for n, p in net.named_parameters()}
     leaves = {n: p.detach().float().requires_grad_(True) for n, p in params.items()}
     xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
-    # rebuild with leaves: simplest is to substitute through functional calls
     t = xr
     for i, blk in enumerate(net.blocks):
         def cbr(t, cname, bname, conv, bn, relu, res=None):
@@ -110,6 +94,18 @@ def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, sha
         o = cbr(o, pre + "conv2", pre + "bn2", blk.conv2, blk.bn2, True)
         t = cbr(o, pre + "conv3", pre + "bn3", blk.conv3, blk.bn3, True, idt)
     t.backward(gy.float().permute(0, 3, 1, 2))
+    return t.detach(), xr.grad, {n: l.grad for n, l in leaves.items()}
+
+
+@pytest.mark.parametrize("planes,shape,stride", [(64, (4, 14, 14), 0), (128, (3, 9, 11), 0), (64, (4, 14, 14), 1),
+                                                 (64, (3, 14, 18), 2)])
+def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, shape, stride):
+    net, x, gy, y1, dx1, g1, folded = _run(True, planes, shape, stride=stride)
+    _, _, _, y0, dx0, g0, none = _run(False, planes, shape, stride=stride)
+    # blocks 0 and 1: their bn3 receives a fused, pre-masked gradient; with a downsample branch its BatchNorm folds too
+    assert folded == (3 if stride else 2) and none == 0
+    assert torch.equal(y1, y0)
+    _, xgrad, rgrads = _reference(net, x, gy)
     # The network runs bf16 activations through three blocks (ReLU masks flip, roundings accumulate): per-element bounds
     # against an fp32 reference are meaningless here.  Tensor-level: the fold differs from the ordinary backward by
     # roundings only (it never rounds dz to bf16), and it is no further from the fp32 reference than the ordinary one.
@@ -118,11 +114,49 @@ def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, sha
 
     assert torch.isfinite(dx1).all()
     assert rel(dx1, dx0) < 2e-2
-    e1, e0 = rel(dx1.permute(0, 3, 1, 2), xr.grad), rel(dx0.permute(0, 3, 1, 2), xr.grad)
+    e1, e0 = rel(dx1.permute(0, 3, 1, 2), xgrad), rel(dx0.permute(0, 3, 1, 2), xgrad)
     assert e1 <= 1.25 * e0 + 1e-3, ("input gradient", e1, e0)
     for n in g1:
         assert torch.isfinite(g1[n]).all(), n
         assert rel(g1[n], g0[n]) < 2e-2, (n, rel(g1[n], g0[n]))
-        ref = leaves[n].grad.reshape(g1[n].shape)
+        ref = rgrads[n].reshape(g1[n].shape)
         e1, e0 = rel(g1[n], ref), rel(g0[n], ref)
         assert e1 <= 1.25 * e0 + 1e-3, (n, e1, e0)
+
+
+@pytest.mark.parametrize("planes,shape,stride", [(64, (4, 14, 14), 0), (128, (3, 9, 11), 0), (64, (3, 14, 18), 2)])
+def test_forward_fold_statistics_from_the_gram_matrix(planes, shape, stride):
+    """The bottleneck tail as ONE GEMM (hip_ops._ConvBnResReluFn): BatchNorm statistics of conv3's output from a^T a and
+    colsum(a), scale folded into the weights, shift + identity + ReLU (+ bit mask) in the epilogue.  Same network with
+    the ordinary conv -> BatchNorm tail: outputs, running statistics and every gradient agree to bf16 rounding."""
+    net1, x, gy, y1, dx1, g1, folded = _run(True, planes, shape, stride=stride, fwd=True)
+    fused = hip_ops.bn_fwd_fold_counts["fused"]
+    net0, _, _, y0, dx0, g0, _ = _run(True, planes, shape, stride=stride, fwd=False)
+    assert fused == (2 if stride else 3)        # the blocks whose residual is the identity
+    assert folded == (4 if stride else 3)       # every bn3 (the last block reduces its own sums) + the downsample BN
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+    assert torch.isfinite(y1).all() and torch.isfinite(dx1).all()
+    assert rel(y1, y0) < 1e-2, rel(y1, y0)
+    assert ((y1 > 0) != (y0 > 0)).float().mean().item() < 2e-2
+    # Gradients: a ReLU that flips where the two outputs straddle zero changes the sums over random upstream gradients by
+    # far more than a rounding, so the two runs are compared through their distance to the fp32 reference (same rounded
+    # parameters): the fused tail must not be further from it than the ordinary one.
+    yr, xgrad, rgrads = _reference(net1, x, gy)
+    e1, e0 = rel(y1.permute(0, 3, 1, 2), yr), rel(y0.permute(0, 3, 1, 2), yr)
+    assert e1 <= 1.25 * e0 + 1e-3, ("output", e1, e0)
+    e1, e0 = rel(dx1.permute(0, 3, 1, 2), xgrad), rel(dx0.permute(0, 3, 1, 2), xgrad)
+    assert e1 <= 1.3 * e0 + 1e-3, ("input gradient", e1, e0)
+    for n in g1:
+        assert torch.isfinite(g1[n]).all(), n
+        ref = rgrads[n].reshape(g1[n].shape)
+        e1, e0 = rel(g1[n], ref), rel(g0[n], ref)
+        assert e1 <= 1.5 * e0 + 5e-3, (n, e1, e0)          # (e0 itself is ~0.1 on the deepest block: mask-flip noise)
+    b1 = dict(net1.named_buffers())
+    for n, b0 in net0.named_buffers():
+        if b0.dtype.is_floating_point:
+            assert rel(b1[n].float(), b0.float()) < 5e-3, (n, rel(b1[n].float(), b0.float()))
+        else:
+            assert torch.equal(b1[n], b0), n
