@@ -67,7 +67,8 @@ template <typename T, int BN, int BKB, int MINB, int PF, bool STATS, bool RACC, 
 __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands");
   static_assert(!FOLD || BNB, "FOLD is a BNB launch");
-  static_assert(!RELUM || (BIAS && RACC && !BNB && !STATS), "RELUM: relu(acc + bias + R) with the ReLU bit mask as a second output");
+  static_assert(!RELUM || (BIAS && (RACC != CAT) && !BNB && !STATS),
+                "RELUM: relu(acc + bias [+ R]) with the ReLU bit mask as a second output; R or a second operand");
   constexpr int BM = 128;
   constexpr int VEC = 8;
   constexpr int BK = BKB / 2;
@@ -469,8 +470,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
           u32x4_t o;
 #pragma unroll
           for (int pr = 0; pr < 4; ++pr) {
-            const uint32_t rm = q.r[i][pr] & pair_mask(q.rbits[i], pr);
-            const uint32_t w = pack_bf16x2(unpack_bf16x2(vv[pr]) + unpack_bf16x2(rm));
+            uint32_t w = vv[pr];
+            if constexpr (RACC) {
+              const uint32_t rm = q.r[i][pr] & pair_mask(q.rbits[i], pr);
+              w = pack_bf16x2(unpack_bf16x2(w) + unpack_bf16x2(rm));
+            }
             const uint32_t m = pair_positive_mask(w);
             o[pr] = w & m;
             bits |= ((m & 1u) | ((m >> 15) & 2u)) << (2 * pr);
@@ -480,10 +484,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_lean_kernel(const IgemmParams 
         } else {
           Vec16<T> v, r;
           v.load(se + row * LDE + ce * 16);
-          r.raw = make_uint4(q.r[i].x, q.r[i].y, q.r[i].z, q.r[i].w);
+          r.raw = RACC ? make_uint4(q.r[i].x, q.r[i].y, q.r[i].z, q.r[i].w) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            const float f = v.get(j) + (((q.rbits[i] >> j) & 1u) ? r.get(j) : 0.f);
+            const float f = v.get(j) + ((RACC && ((q.rbits[i] >> j) & 1u)) ? r.get(j) : 0.f);
             v.set(j, fmaxf(f, 0.f));
             bits |= (v.get(j) > 0.f ? 1u : 0u) << j;
           }
@@ -679,13 +683,14 @@ void launch_lean_epi(const IgemmParams& p, bool strided, hipStream_t stream) {
     launch_lean<T, BN, BKB, MINB, PF, true, false, false, false, 0, false, true>(p, stream);
     return;
   }
+  if (p.flags & kIgemmReluMask) {      // bottleneck tail: relu(acc + shift + identity) + bit mask; two branches as two operands
+    if (p.A2 != nullptr) launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true, false, true, false, true>(p, stream);
+    else launch_lean<T, BN, BKB, MINB, PF, false, true, false, false, 0, true, false, false, false, true>(p, stream);
+    return;
+  }
   if (p.A2 != nullptr) {               // two operands back to back + bias ("bn fold" data gradient), plain or with the reduction
     if (bnb) launch_lean<T, BN, BKB, (BN == 128 && BKB == 64) ? 4 : MINB, PF, false, false, true, false, 0, true, false, true>(p, stream);
     else launch_lean<T, BN, BKB, MINB, PF, false, false, false, false, 0, true, false, true>(p, stream);
-    return;
-  }
-  if (p.flags & kIgemmReluMask) {      // bottleneck tail: relu(acc + shift + identity) + bit mask
-    launch_lean<T, BN, BKB, MINB, PF, false, true, false, false, 0, true, false, false, false, true>(p, stream);
     return;
   }
   if (p.bias != nullptr) {             // Linear forward (gemm_lean_try admits a bias only on the plain variant)
@@ -788,7 +793,7 @@ bool gemm_lean_try(const IgemmParams& p, int dtype, int out_dtype, hipStream_t s
               p.lda2 % 8 || (p.B2 != nullptr && p.ldb2 % 8) || (p.flags & (kIgemmAxf | kIgemmRStrided))))
     return false;
   const bool relum = p.flags & kIgemmReluMask;
-  if (relum && (cat || bnb || p.bias == nullptr || p.R == nullptr || p.relu_mask == nullptr || p.stats != nullptr ||
+  if (relum && (bnb || p.bias == nullptr || (p.R == nullptr) == !cat || p.relu_mask == nullptr || p.stats != nullptr ||
                 p.ldc != p.N || (p.flags & (kIgemmAxf | kIgemmRStrided | kIgemmRelu))))
     return false;
   if (!cat && !relum && p.bias != nullptr && (p.stats != nullptr || p.R != nullptr || bnb)) return false;

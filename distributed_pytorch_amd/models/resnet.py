@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import amp
 from ..nn.modules import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Linear, MaxPool2d, ReLU,
-                          conv_bn_act, conv_bn_relu_maxpool)
+                          conv_bn_act, conv_bn_relu_maxpool, conv_bn_cat_relu)
 from ..ops import functional as F
 
 STEM_PAD_C = 8  # image channels 3 -> 8 on the GPU so every im2col chunk is one 16-byte vector
@@ -81,6 +81,10 @@ class Bottleneck(nn.Module):
         out, identity = conv_bn_act(x, self.conv1, self.bn1, relu=True, skip=True, defer=True)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True, defer=True)
         if self.downsample is not None:
+            # both branches as the two operands of one GEMM (statistics from Gram matrices) where that applies
+            y = conv_bn_cat_relu(out, self.conv3, self.bn3, identity, self.downsample[0], self.downsample[1])
+            if y is not None:
+                return y
             identity = conv_bn_act(identity, self.downsample[0], self.downsample[1], relu=False, defer=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)
 

@@ -296,6 +296,21 @@ def conv_bn_relu_maxpool(x, conv: Conv2d, bn: BatchNorm2d, pool: "MaxPool2d"):
                                 pool.ceil_mode, stats=stats, group=bn.process_group)
 
 
+def conv_bn_cat_relu(a, conv3: Conv2d, bn3: BatchNorm2d, x, convd: Conv2d, bnd: BatchNorm2d):
+    """Tail of a residual block with a downsample branch, ``relu(bn3(conv3(a)) + bnd(convd(x)))``, as ONE two-operand
+    GEMM on the GPU in training mode (``hip_ops._ConvBnCatReluFn``); None when the fused path does not apply -- the
+    caller then runs the two ``conv_bn_act`` calls."""
+    if not (F._on_gpu(a) and bn3.training and bnd.training and bn3.process_group is None and bnd.process_group is None):
+        return None
+    for c in (conv3, convd):
+        if c.groups != 1 or c.bias is not None or not c.needs_input_grad or tuple(c.kernel_size) != (1, 1):
+            return None
+    return F._hip().conv_bn_cat_relu(a, conv3.weight, conv3.stride, conv3.padding, bn3.weight, bn3.bias, bn3.running_mean,
+                                     bn3.running_var, bn3.num_batches_tracked, bn3.momentum, bn3.eps,
+                                     x, convd.weight, convd.stride, convd.padding, bnd.weight, bnd.bias,
+                                     bnd.running_mean, bnd.running_var, bnd.num_batches_tracked, bnd.momentum, bnd.eps)
+
+
 def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu=True, residual=None, skip: bool = False, defer: bool = False,
                 act: Optional[str] = None):
     """conv -> BN(+residual)(+ReLU; ``relu=6``: ReLU6).  ``act`` ("silu", "hardswish", ...): a smooth activation

@@ -423,7 +423,7 @@ def _conv_bn_fold_backward(ctx, fent, pre=None):
     (sh, sw) = ctx.geom[0]
     if (sh, sw) != (1, 1):
         # strided 1x1 branch: everything below is a dense problem on the pixels the convolution really read
-        a = a[:, ::sh, ::sw, :].contiguous()
+        a = pre[3] if (pre is not None and len(pre) > 3) else a[:, ::sh, ::sw, :].contiguous()
     NB, IH, IW, Cx = a.shape
     N = weight.shape[0]
     M = NB * IH * IW
@@ -437,13 +437,17 @@ def _conv_bn_fold_backward(ctx, fent, pre=None):
     else:
         raw = _wgrad_raw(dy, a, M, N, Cx, IH, IW)
         gram, cs = pre[0], pre[1]
-    if part is None:
+    if pre is not None and len(pre) > 4 and pre[4] is not None:
+        dbeta_sum = pre[4]              # (a sibling BatchNorm on the same masked gradient already reduced it)
+    elif part is None:
         dbeta_sum = _colsum(dy.view(M, N))
     else:
         dbeta_sum = torch.empty(N, dtype=torch.float32, device=dev)
         scratch = torch.empty(N, dtype=torch.float32, device=dev)
         partf = _fold(part, N)              # (thousands of 128-row parts: folded by many workgroups first)
         C().bn_bwd_finalize(partf.data_ptr(), partf.shape[0], N, scratch.data_ptr(), dbeta_sum.data_ptr(), st)
+    if hasattr(ctx, "dbeta_out"):
+        ctx.dbeta_out = dbeta_sum
     # ---- BatchNorm coefficients (A, B, K), dgamma / dbeta, and the scaled weight operands
     wlp = conv_weight(weight, dt, Cx)                                 # [N][Cx] as the forward pass used it
     abk = torch.empty((3, N), dtype=torch.float32, device=dev)
@@ -630,6 +634,135 @@ def conv_bn_res_relu(x, weight, stride, padding, gamma, beta, running_mean, runn
                                  float(eps), getattr(x, "_dpa_bn", None))
     if _ConvBnResReluFn.last is not None and torch.is_grad_enabled():
         out._dpa_bn = _ConvBnResReluFn.last     # the consuming convolution stores its data gradient through the mask
+    _ConvBnResReluFn.last = None
+    return out
+
+
+class _ConvBnCatReluFn(torch.autograd.Function):
+    """Tail of a bottleneck WITH a downsample branch in one GEMM over two operands:
+    ``out = relu(BN3(a W3^T) + BNd(x_s Wd^T))`` with both BatchNorms' statistics from Gram matrices (bnfold_fwd), the two
+    scaled weight matrices as the two B operands of the lean GEMM and shift3 + shiftd as its bias.  Neither pre-BatchNorm
+    tensor nor the downsample branch's output is ever written.  Backward: the "bn fold" twice on the same masked gradient."""
+
+    @staticmethod
+    def forward(ctx, a, w3, g3, b3, x, wd, gd, bd, stride, rm3, rv3, nbt3, mom3, eps3, rmd, rvd, nbtd, momd, epsd,
+                bnsrc, compact_ok):
+        NB, IH, IW, C3 = a.shape
+        N = w3.shape[0]
+        M = NB * IH * IW
+        dev, dt, st = a.device, a.dtype, _stream()
+        one = _tap_table(dev, ((0, 0, 0),))
+        xs = x if stride == 1 else x[:, ::stride, ::stride, :].contiguous()
+        Cd = xs.shape[-1]
+
+        def stats(inp, Cc, w, g, b, rm, rv, nbt, mom, eps):
+            gram = _wgrad_raw(inp, inp, M, Cc, Cc, IH, IW)
+            cs = _colsum(inp.view(M, Cc))
+            w32 = w.detach()
+            wg = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+            _igemm(w32, gram, wg, None, None, one, N, Cc, Cc, 1, Cc, Cc, Cc, 1, N, 1, 1, 1, N, dtype=torch.float32,
+                   out_dtype=torch.float32)
+            coef = torch.empty((4, N), dtype=torch.float32, device=dev)
+            wsc = torch.empty((N, Cc), dtype=dt, device=dev)
+            g32, b32 = _f32(g.detach()), _f32(b.detach())
+            C().bnfold_fwd(wg.data_ptr(), w32.data_ptr(), cs.data_ptr(), float(M), g32.data_ptr(), b32.data_ptr(),
+                           float(eps), float(mom), _p(rm), _p(rv), _p(nbt), coef.data_ptr(), wsc.data_ptr(), N, Cc,
+                           _dt(a), st)
+            return gram, cs, wg, coef, wsc
+
+        gram3, cs3, wg3, coef3, wsc3 = stats(a, C3, w3, g3, b3, rm3, rv3, nbt3, mom3, eps3)
+        gramd, csd, wgd, coefd, wscd = stats(xs, Cd, wd, gd, bd, rmd, rvd, nbtd, momd, epsd)
+        shift = coef3[3] + coefd[3]
+        out = torch.empty((NB, IH, IW, N), dtype=dt, device=dev)
+        mask = torch.empty(M * N // _vec(dt), dtype=torch.uint8, device=dev)
+        _igemm(a, wsc3, out, shift, None, one, M, N, C3, 1, C3, C3, N, IH, IW, 1, 1, IH, IW, dtype=dt, out_dtype=dt,
+               cat=(xs, Cd, Cd, wscd, Cd), relu_mask=mask)
+        bn_fwd_fold_counts["fused"] += 1
+        ctx.bnsrc = None
+        if bnsrc is not None:
+            bnsrc.uses += 1
+            if _FUSE_BN_BWD and bnsrc.x.shape == a.shape and bnsrc.x.dtype == a.dtype \
+                    and _FUSE_BN_BWD_MIN <= a.numel() * a.element_size() <= _FUSE_BN_BWD_MAX:
+                ctx.bnsrc = bnsrc
+        ctx.save_for_backward(a, w3, g3, coef3, gram3, cs3, wg3, x, wd, gd, coefd, gramd, csd, wgd,
+                              xs if stride != 1 else None, mask)
+        ctx.b3_ref, ctx.bd_ref = b3, bd
+        ctx.count = float(M)
+        ctx.stride = stride
+        ctx.compact = bool(compact_ok and stride in (2, 4) and N % 32 == 0)
+        ctx.out_ptr = out.data_ptr()
+        ctx.set_materialize_grads(False)
+        _ConvBnResReluFn.last = _BnSrc(out, coef3, 3, mask, True)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w3, g3, coef3, gram3, cs3, wg3, x, wd, gd, coefd, gramd, csd, wgd, xs, mask = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 21
+        part = None
+        fused = _pending_bnred.pop(dy.data_ptr(), None)
+        if fused is not None and len(fused) > 3 and fused[3] and fused[1] == ctx.out_ptr and fused[2] == dy._version \
+                and dy.is_contiguous():
+            part = fused[0]
+        else:
+            ent = _pending_mask.pop(dy.data_ptr(), None)
+            dy = dy if dy.is_contiguous() else dy.contiguous()
+            if ent is not None and ent[1] == dy._version and ent[2] == _generation \
+                    and ent[0].numel() * _vec(dy.dtype) == dy.numel():
+                dy = apply_bit_mask(dy, ent[0])
+            dy = apply_bit_mask(dy, mask)
+        s_ = ctx.stride
+        fctx3 = types.SimpleNamespace(saved_tensors=(a, w3, None), geom=((1, 1), (0, 0), False, True, False),
+                                      bnsrc=ctx.bnsrc, compact=False, dbeta_out=None,
+                                      needs_input_grad=(ctx.needs_input_grad[0], ctx.needs_input_grad[1]))
+        ctx.bnsrc = None
+        da = _conv_bn_fold_backward(fctx3, (None, dy, part, coef3, g3, ctx.b3_ref, ctx.count, _generation),
+                                    pre=(gram3, cs3, wg3))[0]
+        fctxd = types.SimpleNamespace(saved_tensors=(x, wd, None), geom=((s_, s_), (0, 0), False, True, False),
+                                      bnsrc=None, compact=ctx.compact,
+                                      needs_input_grad=(ctx.needs_input_grad[4], ctx.needs_input_grad[5]))
+        dx = _conv_bn_fold_backward(fctxd, (None, dy, part, coefd, gd, ctx.bd_ref, ctx.count, _generation),
+                                    pre=(gramd, csd, wgd, xs, fctx3.dbeta_out))[0]
+        return (da, None, None, None, dx) + (None,) * 16
+
+
+def conv_bn_cat_relu(a, w3, stride3, padding3, g3, b3, rm3, rv3, nbt3, mom3, eps3,
+                     x, wd, strided, paddingd, gd, bd, rmd, rvd, nbtd, momd, epsd):
+    """``relu(batch_norm(conv1x1(a)) + batch_norm(conv1x1_stride_s(x)))`` (training mode) as one two-operand GEMM, or None
+    when this is not a launch the fused path takes."""
+    if not _BN_FWD_FOLD or mom3 is None or momd is None or rm3 is None or rmd is None:
+        return None
+    if getattr(a, "_dpa_deferred_coef", None) is not None and not getattr(a, "_dpa_deferred_relu", False):
+        return None
+    if getattr(x, "_dpa_deferred_coef", None) is not None:
+        return None
+    sd = tuple(strided)
+    if tuple(stride3) != (1, 1) or sd[0] != sd[1] or sd[0] not in (1, 2) or tuple(paddingd) != (0, 0):
+        return None
+    if not _bn_fold_eligible(a, w3, None, stride3, padding3, False, True, True, False) \
+            or not _bn_fold_eligible(x, wd, None, sd, paddingd, False, True, True, False):
+        return None
+    NB, IH, IW, C3 = a.shape
+    N = w3.shape[0]
+    if wd.shape[0] != N or N % 128 or x.dtype != a.dtype or not x.is_contiguous():
+        return None
+    if x.shape[0] != NB or (x.shape[1] + sd[0] - 1) // sd[0] != IH or (x.shape[2] + sd[0] - 1) // sd[0] != IW:
+        return None
+    if not all(t.requires_grad for t in (g3, b3, gd, bd)):
+        return None
+    grad_sink.note_use(w3, None)
+    grad_sink.note_use(wd, None)
+    grad_sink.note_use(g3, b3)
+    grad_sink.note_use(gd, bd)
+    if getattr(a, "_dpa_deferred_coef", None) is not None:
+        a = materialize(a)
+    a = a if a.is_contiguous() else a.contiguous()
+    out = _ConvBnCatReluFn.apply(a, w3, g3, b3, x, wd, gd, bd, sd[0], rm3, rv3, nbt3, float(mom3), float(eps3),
+                                 rmd, rvd, nbtd, float(momd), float(epsd), getattr(a, "_dpa_bn", None),
+                                 bool(getattr(x, "_dpa_compact_ok", False)))
+    if _ConvBnResReluFn.last is not None and torch.is_grad_enabled():
+        out._dpa_bn = _ConvBnResReluFn.last
     _ConvBnResReluFn.last = None
     return out
 

@@ -124,7 +124,8 @@ def test_bn_fold_matches_the_unfolded_backward_and_an_fp32_reference(planes, sha
         assert e1 <= 1.25 * e0 + 1e-3, (n, e1, e0)
 
 
-@pytest.mark.parametrize("planes,shape,stride", [(64, (4, 14, 14), 0), (128, (3, 9, 11), 0), (64, (3, 14, 18), 2)])
+@pytest.mark.parametrize("planes,shape,stride", [(64, (4, 14, 14), 0), (128, (3, 9, 11), 0), (64, (4, 14, 14), 1),
+                                                 (64, (3, 14, 18), 2)])
 def test_forward_fold_statistics_from_the_gram_matrix(planes, shape, stride):
     """The bottleneck tail as ONE GEMM (hip_ops._ConvBnResReluFn): BatchNorm statistics of conv3's output from a^T a and
     colsum(a), scale folded into the weights, shift + identity + ReLU (+ bit mask) in the epilogue.  Same network with
@@ -132,7 +133,7 @@ def test_forward_fold_statistics_from_the_gram_matrix(planes, shape, stride):
     net1, x, gy, y1, dx1, g1, folded = _run(True, planes, shape, stride=stride, fwd=True)
     fused = hip_ops.bn_fwd_fold_counts["fused"]
     net0, _, _, y0, dx0, g0, _ = _run(True, planes, shape, stride=stride, fwd=False)
-    assert fused == (2 if stride else 3)        # the blocks whose residual is the identity
+    assert fused == 3                           # identity blocks (one operand + R) and the downsample block (two operands)
     assert folded == (4 if stride else 3)       # every bn3 (the last block reduces its own sums) + the downsample BN
 
     def rel(a, b):
