@@ -439,7 +439,10 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
     const int ncol = n0 + wc * 64 + ck * 8;           // first of this lane's 8 channels
     const bool col_ok = ncol < p.N;                   // N % 8 == 0: whole chunks
     // global addresses = a wave-uniform base (+ a uniform row-group step) + ONE 32-bit lane offset
-    const size_t cb = ((size_t)mbase * p.ldc + (size_t)(n0 + wc * 64)) * sizeof(T);
+    // (a part that does not exist -- rows past M, or a 64-column block past N -- requests its epilogue operands at offset
+    // 0 of their tensors: its lanes are all "not ok" and would otherwise read up to 255 rows past the end)
+    const bool part_ok = rows > 0 && n0 + wc * 64 < p.N;      // wave uniform
+    const size_t cb = part_ok ? ((size_t)mbase * p.ldc + (size_t)(n0 + wc * 64)) * sizeof(T) : (size_t)0;
     const uint32_t loff = (uint32_t)((rsub * p.ldc + ck * 8) * (int)sizeof(T));
     const uint32_t rstep = 8u * (uint32_t)p.ldc * (uint32_t)sizeof(T);
     uint4 px[16];
