@@ -447,29 +447,60 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
     const uint32_t rstep = 8u * (uint32_t)p.ldc * (uint32_t)sizeof(T);
     uint4 px[16];
     uint32_t pbits[16];
-    if constexpr (EPI == kEpiBnb || EPI == kEpiXMask) {
-      const char* xg = reinterpret_cast<const char*>(p.bn_x) + cb;
-      const uint8_t* bits = reinterpret_cast<const uint8_t*>(p.bn_z) + (cb >> 4);
-      const bool want_bits = EPI == kEpiBnb && (p.bn_relu & 3) == 3;
-      const bool fold = EPI == kEpiBnb && (p.flags & kIgemmBnFold);     // bn_x is not read (kernels.h)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const bool ok = col_ok && i * 8 + rsub < rows;
-        const uint32_t lo = ok ? loff : 0u;              // (row 0 of an existing part always exists)
-        const size_t ro = ok ? (size_t)i * rstep : 0;
-        pbits[i] = want_bits ? bits[(ro >> 4) + (lo >> 4)] : 0xffu;
-      }
-      if (!fold) {
+    // epilogue operands (BN input / ReLU source, mask bits) are requested in two halves: rows 0..63 before the accumulators
+    // go through LDS, rows 64..127 behind that -- all 16 row pieces next to the live accumulators spilled 43 VGPRs
+    auto request = [&](int first, int last) __attribute__((always_inline)) {
+      if constexpr (EPI == kEpiBnb || EPI == kEpiXMask) {
+        const char* xg = reinterpret_cast<const char*>(p.bn_x) + cb;
+        const uint8_t* bits = reinterpret_cast<const uint8_t*>(p.bn_z) + (cb >> 4);
+        const bool want_bits = EPI == kEpiBnb && (p.bn_relu & 3) == 3;
+        const bool fold = EPI == kEpiBnb && (p.flags & kIgemmBnFold);     // bn_x is not read (kernels.h)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+          if (i < first || i >= last) continue;
           const bool ok = col_ok && i * 8 + rsub < rows;
-          px[i] = *reinterpret_cast<const uint4*>(xg + (ok ? (size_t)i * rstep : 0) + (ok ? loff : 0u));
+          const uint32_t lo = ok ? loff : 0u;              // (row 0 of an existing part always exists)
+          const size_t ro = ok ? (size_t)i * rstep : 0;
+          pbits[i] = want_bits ? bits[(ro >> 4) + (lo >> 4)] : 0xffu;
         }
-      } else {
+        if (!fold) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) px[i] = make_uint4(0u, 0u, 0u, 0u);
+          for (int i = 0; i < 16; ++i) {
+            if (i < first || i >= last) continue;
+            const bool ok = col_ok && i * 8 + rsub < rows;
+            px[i] = *reinterpret_cast<const uint4*>(xg + (ok ? (size_t)i * rstep : 0) + (ok ? loff : 0u));
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i < first || i >= last) continue;
+            px[i] = make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+      }
+    };
+    // per-channel BN coefficients FIRST: vmcnt retires in order, requested behind the row operands they would make row 0
+    // wait for the last request (profiles/r3/lean_epilogue_vmcnt.md)
+    float bmu[8], bis[8], bsc[8], bsh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bmu[j] = bis[j] = bsc[j] = bsh[j] = 0.f;
+    int bn_mode = 0;
+    bool bn_clip = false;
+    if constexpr (EPI == kEpiBnb) {
+      bn_mode = p.bn_relu & 3;
+      bn_clip = p.bn_relu & 4;
+      if (!(p.flags & kIgemmBnFold)) {
+        const float* cf = p.bn_coef + (col_ok ? ncol : 0);      // [4][stats_ld]: mean, invstd, scale, shift
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bmu[j] = cf[j];
+          bis[j] = cf[p.stats_ld + j];
+          bsc[j] = bn_mode == 2 ? cf[2 * (long)p.stats_ld + j] : 0.f;
+          bsh[j] = bn_mode == 2 ? cf[3 * (long)p.stats_ld + j] : 0.f;
+        }
       }
     }
+    request(0, 8);
     float bv[2][4][4];
     if constexpr (EPI == kEpiPlain) {
 #pragma unroll
@@ -514,6 +545,7 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    request(8, 16);
 
     float s1[8], s2[8], kshift[8];
 #pragma unroll
@@ -523,21 +555,6 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
       k0.load(my + ck * 16);
 #pragma unroll
       for (int j = 0; j < 8; ++j) kshift[j] = k0.get(j);
-    }
-    float bmu[8], bis[8], bsc[8], bsh[8];
-    int bn_mode = 0;
-    bool bn_clip = false;
-    if constexpr (EPI == kEpiBnb) {
-      bn_mode = p.bn_relu & 3;
-      bn_clip = p.bn_relu & 4;
-      const float* cf = p.bn_coef + (col_ok ? ncol : 0);      // [4][stats_ld]: mean, invstd, scale, shift
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bmu[j] = cf[j];
-        bis[j] = cf[p.stats_ld + j];
-        bsc[j] = bn_mode == 2 ? cf[2 * (long)p.stats_ld + j] : 0.f;
-        bsh[j] = bn_mode == 2 ? cf[3 * (long)p.stats_ld + j] : 0.f;
-      }
     }
     char* cg = reinterpret_cast<char*>(p.C) + cb;
     const bool nt_store = p.flags & kIgemmNtStore;
