@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round-2 matrix (one box): "args -> img/s ms peak_GB"; usage: bench_final_matrix.sh <part 1|2>
-mkdir -p gpurun_out/r2
-out=gpurun_out/r2/bench_matrix_final_$1.txt; : > $out
+mkdir -p gpurun_out/${ROUND:-r2}
+out=gpurun_out/${ROUND:-r2}/bench_matrix_final_$1.txt; : > $out
 run() { timeout -k 10 240 python bench.py "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '->', d['value'], d['ms_per_step'], d['config'].get('peak_mem_gb'))" | tee -a $out || exit 1; }
 if [ "$1" = "1" ]; then
 run --steps 20 --warmup 8

@@ -575,7 +575,9 @@ class _ConvBnResReluFn(torch.autograd.Function):
         ctx.count = float(M)
         ctx.out_ptr = out.data_ptr()
         ctx.set_materialize_grads(False)
-        _ConvBnResReluFn.last = _BnSrc(out, coef, 3, mask, True)
+        # (a detached alias, not `out` itself: the object ends up as an attribute OF out, and a reference cycle would keep
+        # every block output alive until the cyclic collector runs)
+        _ConvBnResReluFn.last = _BnSrc(out.detach(), coef, 3, mask, True)
         return out
 
     @staticmethod
@@ -692,7 +694,7 @@ class _ConvBnCatReluFn(torch.autograd.Function):
         ctx.compact = bool(compact_ok and stride in (2, 4) and N % 32 == 0)
         ctx.out_ptr = out.data_ptr()
         ctx.set_materialize_grads(False)
-        _ConvBnResReluFn.last = _BnSrc(out, coef3, 3, mask, True)
+        _ConvBnResReluFn.last = _BnSrc(out.detach(), coef3, 3, mask, True)      # (detached: see _ConvBnResReluFn)
         return out
 
     @staticmethod
