@@ -351,6 +351,10 @@ _BN_FOLD_MIN_RATIO = float(os.environ.get("DPA_BN_FOLD_MIN_RATIO", "2"))
 # size (MiB of the BatchNorm input) from which it is taken: measured on ResNet-50 at batch 1024, the 7x7 blocks (205 MiB)
 # lose 0.1 ms to the extra small launches, everything larger gains (profiles/r3/bn_fold.txt)
 _BN_FOLD_MIN_MB = float(os.environ.get("DPA_BN_FOLD_MIN_MB", "300"))
+# ... and from half that size where the convolution's input has at most 256 channels: the fold's own cost is launches plus
+# work on C x C matrices, so at batch 256 the 28x28 128 -> 512 blocks (205 MiB, C = 128) gain 3 % of the step while at batch
+# 1024 the 7x7 512 -> 2048 ones (also 205 MiB, C = 512) lose (profiles/r3_notes.md)
+_BN_FOLD_NARROW_C = 256
 # data_ptr of the NaN token a folded BatchNorm returned as "the gradient of its input" -> (token, dy (ReLU-masked), partial
 # slab with sum dy_m per part, BN coef [4][N], gamma, beta parameter, count, generation).  Consumed by _ConvFn.backward of
 # the 1x1 convolution that produced the BatchNorm's input.
@@ -374,7 +378,8 @@ def _bn_fold_eligible(x, weight, bias, stride, padding, relu, want_stats, needs_
     Cx = x.shape[-1]
     if Cx != Cw or Cx % 64 or K % 64 or K < _BN_FOLD_MIN_RATIO * Cx:
         return False
-    if x.numel() // Cx // (stride[0] * stride[1]) * K * x.element_size() < _BN_FOLD_MIN_MB * 2 ** 20:
+    min_mb = _BN_FOLD_MIN_MB * (0.5 if Cx <= _BN_FOLD_NARROW_C else 1.0)
+    if x.numel() // Cx // (stride[0] * stride[1]) * K * x.element_size() < min_mb * 2 ** 20:
         return False
     return grad_sink.sink_of(weight) is not None
 
