@@ -230,6 +230,12 @@ PYBIND11_MODULE(_C, m) {
                          ptr<const float>(mean), ptr<const float>(invstd), relu, ptr<const float>(scale),
                          ptr<const float>(shift), ptr<float>(partial), nblk, st(s));
   });
+  m.def("bn_apply_colsum_parts", &bn_apply_colsum_parts);
+  m.def("bn_apply_colsum", [](uintptr_t x, uintptr_t y, long M, int C, int dtype, uintptr_t scale, uintptr_t shift,
+                              uintptr_t part, int nparts, uintptr_t s) {
+    bn_apply_colsum_launch(ptr<const void>(x), ptr<void>(y), M, C, dtype, ptr<const float>(scale), ptr<const float>(shift),
+                           ptr<float>(part), nparts, st(s));
+  });
   m.def("bn_bwd_finalize", [](uintptr_t partial, int nparts, int C, uintptr_t dgamma, uintptr_t dbeta, uintptr_t s) {
     bn_bwd_finalize_launch(ptr<const float>(partial), nparts, C, ptr<float>(dgamma), ptr<float>(dbeta), st(s));
   });

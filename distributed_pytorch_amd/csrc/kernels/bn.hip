@@ -787,6 +787,64 @@ __global__ __launch_bounds__(256, DPA_BN_OCC) void bn_apply_fast_kernel(
   }
 }
 
+// relu(scale * x + shift) like bn_apply_fast_kernel<T, 0, false, NT, U>, plus the COLUMN SUMS of what it stores: every
+// workgroup leaves one row of partial sums (slab [grid][2][C], second row zero) -- the colsum(a) that the "forward fold"
+// needs (BatchNorm statistics of the next 1x1 convolution from a^T a and colsum(a), hip_ops._ConvBnResReluFn) without
+// another pass over a.  256 % cc == 0: a thread keeps one channel chunk.
+template <typename T, bool NT, int U>
+__global__ __launch_bounds__(256, DPA_BN_OCC) void bn_apply_colsum_kernel(
+    const T* __restrict__ x, T* __restrict__ y, long nchunks, int cc, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ part) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float red[256 * VEC];
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(threadIdx.x % cc) * VEC;
+  float scv[VEC], shv[VEC], acc[VEC];
+  load_coef<VEC>(scale, c0, scv);
+  load_coef<VEC>(shift, c0, shv);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  auto one = [&](const Vec16<T>& vx, long q) {
+    Vec16<T> vo;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      vo.set(j, fmaxf(vx.get(j) * scv[j] + shv[j], 0.f));
+      acc[j] += vo.get(j);                       // the value as stored
+    }
+    if constexpr (NT) vo.store_nt(y + q * VEC);
+    else vo.store(y + q * VEC);
+  };
+  for (; i + (U - 1) * stride < nchunks; i += U * stride) {
+    Vec16<T> vx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (NT) vx[u].load_nt(x + (i + u * stride) * VEC);
+      else vx[u].load(x + (i + u * stride) * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(vx[u], i + u * stride);
+  }
+  for (; i < nchunks; i += stride) {
+    Vec16<T> vx;
+    vx.load(x + i * VEC);
+    one(vx, i);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = acc[j];
+  __syncthreads();
+  if ((int)threadIdx.x < cc) {
+    const int C = cc * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float s = 0.f;
+      for (int k = threadIdx.x; k < 256; k += cc) s += red[k * VEC + j];
+      part[((size_t)blockIdx.x * 2 + 0) * C + c0 + j] = s;
+      part[((size_t)blockIdx.x * 2 + 1) * C + c0 + j] = 0.f;
+    }
+  }
+}
+
 // dx = A * dy_m + B * x + K, optional second output dres = dy_m; RM = the mask source (relu & 3, see col_reduce_kernel)
 template <typename T, int RM, bool DRES, bool NT, int U>
 __global__ __launch_bounds__(256, DPA_BN_OCC) void bn_bwd_apply_fast_kernel(
@@ -1009,6 +1067,28 @@ void bn_eval_coeffs_launch(const float* gamma, const float* beta, const float* r
                            hipStream_t s) {
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, gamma, beta,
                      running_mean, running_var, eps, C, scale, shift);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+// Workgroups (= rows of the partial slab [n][2][C]) of bn_apply_colsum_launch; 0: the launch is not covered
+int bn_apply_colsum_parts(long M, int C, int dtype) {
+  if (dtype == kF32 || C % 8 != 0 || C / 8 > 256 || 256 % (C / 8) != 0 || M <= 0) return 0;
+  return grid_for(M * (C / 8), C / 8);
+}
+
+void bn_apply_colsum_launch(const void* x, void* y, long M, int C, int dtype, const float* scale, const float* shift,
+                            float* part, int nparts, hipStream_t s) {
+  if (nparts <= 0 || nparts != bn_apply_colsum_parts(M, C, dtype))
+    throw std::invalid_argument("bn_apply_colsum: slab rows must come from bn_apply_colsum_parts");
+  const long nchunks = M * (C / 8);
+  const bool nt = nt_auto(nchunks * 16, 1);
+  if (dtype == kBF16) {
+    if (nt) hipLaunchKernelGGL((bn_apply_colsum_kernel<bf16_t, true, DPA_BN_U>), dim3(nparts), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nchunks, C / 8, scale, shift, part);
+    else hipLaunchKernelGGL((bn_apply_colsum_kernel<bf16_t, false, DPA_BN_U>), dim3(nparts), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, nchunks, C / 8, scale, shift, part);
+  } else {
+    if (nt) hipLaunchKernelGGL((bn_apply_colsum_kernel<f16_t, true, DPA_BN_U>), dim3(nparts), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, nchunks, C / 8, scale, shift, part);
+    else hipLaunchKernelGGL((bn_apply_colsum_kernel<f16_t, false, DPA_BN_U>), dim3(nparts), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, nchunks, C / 8, scale, shift, part);
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 

@@ -187,6 +187,10 @@ void bn_bwd_reduce_launch(const void* dy, const void* x, const void* y, long M, 
                           const float* mean, const float* invstd, int relu /* 0 | 1: mask from y | 2: from x */,
                           const float* scale, const float* shift, float* partial, int nblk, hipStream_t s);
 // sums partials -> dgamma, dbeta (fp32 [C]) and the two per-channel means used by the apply pass
+// relu(scale * x + shift) + per-workgroup column sums of the stored result (slab [parts][2][C], row 1 zero)
+int bn_apply_colsum_parts(long M, int C, int dtype);
+void bn_apply_colsum_launch(const void* x, void* y, long M, int C, int dtype, const float* scale, const float* shift,
+                            float* part, int nparts, hipStream_t s);
 void bn_bwd_finalize_launch(const float* partial, int nparts, int C, float* dgamma, float* dbeta,
                             hipStream_t s);
 // fold partials -> dgamma, dbeta and (coef != nullptr) the apply coefficients [5][C], one launch

@@ -539,12 +539,14 @@ def _conv_bn_fold_backward(ctx, fent, pre=None):
 # the "bn fold" above with the Gram matrix, colsum(a) and W gram kept from forward.
 # ------------------------------------------------------------------------------------------
 _BN_FWD_FOLD = os.environ.get("DPA_BN_FWD_FOLD", "1") == "1"
+# colsum(a) from the pass that materialises a (bn_apply_colsum) instead of a reduction pass of its own
+_COLSUM_IN_APPLY = os.environ.get("DPA_COLSUM_IN_APPLY", "1") == "1"
 bn_fwd_fold_counts = {"fused": 0}
 
 
 class _ConvBnResReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, weight, gamma, beta, residual, running_mean, running_var, nbt, momentum, eps, bnsrc):
+    def forward(ctx, a, weight, gamma, beta, residual, running_mean, running_var, nbt, momentum, eps, bnsrc, cs_pre=None):
         NB, IH, IW, Cx = a.shape
         N = weight.shape[0]
         M = NB * IH * IW
@@ -552,7 +554,7 @@ class _ConvBnResReluFn(torch.autograd.Function):
         one = _tap_table(dev, ((0, 0, 0),))
         # ---- statistics of z = a W^T from a^T a and colsum(a)
         gram = _wgrad_raw(a, a, M, Cx, Cx, IH, IW)
-        cs = _colsum(a.view(M, Cx))
+        cs = cs_pre if cs_pre is not None else _colsum(a.view(M, Cx))
         w32 = weight.detach()               # [N, Cx, 1, 1]: N rows of Cx in either memory format
         wg = torch.empty((N, Cx), dtype=torch.float32, device=dev)
         _igemm(w32, gram, wg, None, None, one, N, Cx, Cx, 1, Cx, Cx, Cx, 1, N, 1, 1, 1, N, dtype=torch.float32,
@@ -589,7 +591,7 @@ class _ConvBnResReluFn(torch.autograd.Function):
     def backward(ctx, dy):
         a, weight, gamma, coef, mask, gram, cs, wg = ctx.saved_tensors
         if dy is None:
-            return (None,) * 11
+            return (None,) * 12
         part = None
         fused = _pending_bnred.pop(dy.data_ptr(), None)
         if fused is not None and len(fused) > 3 and fused[3] and fused[1] == ctx.out_ptr and fused[2] == dy._version \
@@ -609,7 +611,7 @@ class _ConvBnResReluFn(torch.autograd.Function):
         ctx.bnsrc = None
         da = _conv_bn_fold_backward(fctx, fent, pre=(gram, cs, wg))[0]
         dres = dy if ctx.needs_input_grad[4] else None
-        return da, None, None, None, dres, None, None, None, None, None, None
+        return da, None, None, None, dres, None, None, None, None, None, None, None
 
 
 _ConvBnResReluFn.last = None
@@ -635,10 +637,10 @@ def conv_bn_res_relu(x, weight, stride, padding, gamma, beta, running_mean, runn
     grad_sink.note_use(weight, None)
     grad_sink.note_use(gamma, beta)
     if getattr(x, "_dpa_deferred_coef", None) is not None:
-        x = materialize(x)          # the GEMMs of both directions run on the normalised activation itself
+        x = materialize(x, want_colsum=True)    # the GEMMs of both directions run on the normalised activation itself
     x = x if x.is_contiguous() else x.contiguous()
     out = _ConvBnResReluFn.apply(x, weight, gamma, beta, residual, running_mean, running_var, nbt, float(momentum),
-                                 float(eps), getattr(x, "_dpa_bn", None))
+                                 float(eps), getattr(x, "_dpa_bn", None), getattr(x, "_dpa_colsum", None))
     if _ConvBnResReluFn.last is not None and torch.is_grad_enabled():
         out._dpa_bn = _ConvBnResReluFn.last     # the consuming convolution stores its data gradient through the mask
     _ConvBnResReluFn.last = None
@@ -653,7 +655,7 @@ class _ConvBnCatReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, w3, g3, b3, x, wd, gd, bd, stride, rm3, rv3, nbt3, mom3, eps3, rmd, rvd, nbtd, momd, epsd,
-                bnsrc, compact_ok):
+                bnsrc, compact_ok, cs_pre=None):
         NB, IH, IW, C3 = a.shape
         N = w3.shape[0]
         M = NB * IH * IW
@@ -662,9 +664,9 @@ class _ConvBnCatReluFn(torch.autograd.Function):
         xs = x if stride == 1 else x[:, ::stride, ::stride, :].contiguous()
         Cd = xs.shape[-1]
 
-        def stats(inp, Cc, w, g, b, rm, rv, nbt, mom, eps):
+        def stats(inp, Cc, w, g, b, rm, rv, nbt, mom, eps, cs=None):
             gram = _wgrad_raw(inp, inp, M, Cc, Cc, IH, IW)
-            cs = _colsum(inp.view(M, Cc))
+            cs = cs if cs is not None else _colsum(inp.view(M, Cc))
             w32 = w.detach()
             wg = torch.empty((N, Cc), dtype=torch.float32, device=dev)
             _igemm(w32, gram, wg, None, None, one, N, Cc, Cc, 1, Cc, Cc, Cc, 1, N, 1, 1, 1, N, dtype=torch.float32,
@@ -677,7 +679,7 @@ class _ConvBnCatReluFn(torch.autograd.Function):
                            _dt(a), st)
             return gram, cs, wg, coef, wsc
 
-        gram3, cs3, wg3, coef3, wsc3 = stats(a, C3, w3, g3, b3, rm3, rv3, nbt3, mom3, eps3)
+        gram3, cs3, wg3, coef3, wsc3 = stats(a, C3, w3, g3, b3, rm3, rv3, nbt3, mom3, eps3, cs_pre)
         gramd, csd, wgd, coefd, wscd = stats(xs, Cd, wd, gd, bd, rmd, rvd, nbtd, momd, epsd)
         shift = coef3[3] + coefd[3]
         out = torch.empty((NB, IH, IW, N), dtype=dt, device=dev)
@@ -706,7 +708,7 @@ class _ConvBnCatReluFn(torch.autograd.Function):
     def backward(ctx, dy):
         a, w3, g3, coef3, gram3, cs3, wg3, x, wd, gd, coefd, gramd, csd, wgd, xs, mask = ctx.saved_tensors
         if dy is None:
-            return (None,) * 21
+            return (None,) * 22
         part = None
         fused = _pending_bnred.pop(dy.data_ptr(), None)
         if fused is not None and len(fused) > 3 and fused[3] and fused[1] == ctx.out_ptr and fused[2] == dy._version \
@@ -731,7 +733,7 @@ class _ConvBnCatReluFn(torch.autograd.Function):
                                       needs_input_grad=(ctx.needs_input_grad[4], ctx.needs_input_grad[5]))
         dx = _conv_bn_fold_backward(fctxd, (None, dy, part, coefd, gd, ctx.bd_ref, ctx.count, _generation),
                                     pre=(gramd, csd, wgd, xs, fctx3.dbeta_out))[0]
-        return (da, None, None, None, dx) + (None,) * 16
+        return (da, None, None, None, dx) + (None,) * 17
 
 
 def conv_bn_cat_relu(a, w3, stride3, padding3, g3, b3, rm3, rv3, nbt3, mom3, eps3,
@@ -763,11 +765,11 @@ def conv_bn_cat_relu(a, w3, stride3, padding3, g3, b3, rm3, rv3, nbt3, mom3, eps
     grad_sink.note_use(g3, b3)
     grad_sink.note_use(gd, bd)
     if getattr(a, "_dpa_deferred_coef", None) is not None:
-        a = materialize(a)
+        a = materialize(a, want_colsum=True)
     a = a if a.is_contiguous() else a.contiguous()
     out = _ConvBnCatReluFn.apply(a, w3, g3, b3, x, wd, gd, bd, sd[0], rm3, rv3, nbt3, float(mom3), float(eps3),
                                  rmd, rvd, nbtd, float(momd), float(epsd), getattr(a, "_dpa_bn", None),
-                                 bool(getattr(x, "_dpa_compact_ok", False)))
+                                 bool(getattr(x, "_dpa_compact_ok", False)), getattr(a, "_dpa_colsum", None))
     if _ConvBnResReluFn.last is not None and torch.is_grad_enabled():
         out._dpa_bn = _ConvBnResReluFn.last
     _ConvBnResReluFn.last = None
@@ -1176,27 +1178,46 @@ class _MaterializeFn(torch.autograd.Function):
     """relu(scale * x + shift) of a deferred BatchNorm + ReLU for a consumer that cannot apply it on load.  The
     BatchNorm's own backward recomputes the ReLU mask from x, so the gradient passes through unchanged."""
 
+    last_colsum = None
+
     @staticmethod
-    def forward(ctx, x, coef):
+    def forward(ctx, x, coef, want_colsum=False):
         y = torch.empty_like(x)
         Cc = x.shape[-1]
-        C().bn_apply(x.data_ptr(), 0, y.data_ptr(), x.numel() // Cc, Cc, _dt(x), coef[2].data_ptr(), coef[3].data_ptr(),
+        M = x.numel() // Cc
+        _MaterializeFn.last_colsum = None
+        nparts = C().bn_apply_colsum_parts(M, Cc, _dt(x)) if (want_colsum and x.is_contiguous()) else 0
+        if nparts > 0:
+            # the same pass also leaves the column sums of what it writes (the forward fold's colsum(a))
+            part = torch.empty((nparts, 2, Cc), dtype=torch.float32, device=x.device)
+            C().bn_apply_colsum(x.data_ptr(), y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(), coef[3].data_ptr(),
+                                part.data_ptr(), nparts, _stream())
+            s1 = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            s2 = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            C().bn_bwd_finalize(part.data_ptr(), nparts, Cc, s2.data_ptr(), s1.data_ptr(), _stream())
+            _MaterializeFn.last_colsum = s1
+            return y
+        C().bn_apply(x.data_ptr(), 0, y.data_ptr(), M, Cc, _dt(x), coef[2].data_ptr(), coef[3].data_ptr(),
                      1, _stream(), 0, 0, 0)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return dy, None
+        return dy, None, None
 
 
-def materialize(x: torch.Tensor) -> torch.Tensor:
-    """The normalised activation behind a deferred BatchNorm + ReLU output (identity for ordinary tensors)."""
+def materialize(x: torch.Tensor, want_colsum: bool = False) -> torch.Tensor:
+    """The normalised activation behind a deferred BatchNorm + ReLU output (identity for ordinary tensors).
+    ``want_colsum``: the pass also reduces the column sums of its result (``y._dpa_colsum``, fp32 [C])."""
     coef = getattr(x, "_dpa_deferred_coef", None)
     if coef is None:
         return x
     if not getattr(x, "_dpa_deferred_relu", False):
         raise ValueError("a deferred activation-free BatchNorm output can only be the `residual` of another BatchNorm")
-    y = _MaterializeFn.apply(x, coef)
+    y = _MaterializeFn.apply(x, coef, bool(want_colsum and _COLSUM_IN_APPLY))
+    if _MaterializeFn.last_colsum is not None:
+        y._dpa_colsum = _MaterializeFn.last_colsum
+        _MaterializeFn.last_colsum = None
     bn = getattr(x, "_dpa_bn", None)
     if bn is not None:
         y._dpa_bn = bn

@@ -192,3 +192,25 @@ def test_forward_fold_keeps_no_block_output_alive_between_steps():
         hip_ops._BN_FOLD, hip_ops._BN_FOLD_MIN_MB, hip_ops._BN_FWD_FOLD = old
     assert hip_ops.bn_fwd_fold_counts["fused"] == 15
     assert used[4] <= used[1] + (1 << 20), used
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,Cc", [(1000, 64), (4099, 128), (777, 256), (50000, 512), (300000, 64)])
+def test_bn_apply_with_column_sums(M, Cc, dtype):
+    """bn_apply_colsum: relu(scale * x + shift) bit-identical to the ordinary apply pass, column sums of the STORED values."""
+    C = hip_ops.C()
+    torch.manual_seed(3)
+    x = (torch.randn(M, Cc, device=DEV) * 1.3 + 0.2).to(dtype)
+    scale = torch.rand(Cc, device=DEV) + 0.5
+    shift = torch.randn(Cc, device=DEV) * 0.3
+    st = torch.cuda.current_stream().cuda_stream
+    y0 = torch.empty_like(x)
+    C.bn_apply(x.data_ptr(), 0, y0.data_ptr(), M, Cc, hip_ops._dt(x), scale.data_ptr(), shift.data_ptr(), 1, st, 0, 0, 0)
+    n = C.bn_apply_colsum_parts(M, Cc, hip_ops._dt(x))
+    assert n > 0
+    y1 = torch.empty_like(x)
+    part = torch.full((n, 2, Cc), float("nan"), device=DEV)
+    C.bn_apply_colsum(x.data_ptr(), y1.data_ptr(), M, Cc, hip_ops._dt(x), scale.data_ptr(), shift.data_ptr(), part.data_ptr(), n, st)
+    assert torch.equal(y1, y0)
+    assert torch.equal(part[:, 1], torch.zeros_like(part[:, 1]))
+    assert_close(part[:, 0].double().sum(0).float(), y0.double().sum(0).float(), torch.float32, scale=20, what="column sums")
