@@ -15,12 +15,13 @@ for (H, Cin, Cout) in [(56, 256, 64), (28, 512, 128), (14, 1024, 256), (7, 2048,
     bits = torch.randint(0, 256, (N * H * H * Cin // 8,), dtype=torch.uint8, device="cuda")
     other = torch.randn(N, H, H, Cin, device="cuda").bfloat16()
     row = []
-    for a in (0, 8, 9, 10, 11):
-        C.igemm_set_lean_ablate(a)
+    for a in (0, 100):
+        C.igemm_set_lean(3 if a == 100 else -1)
         def f():
             hip_ops.conv_dgrad(dy, w, tuple(bn_x.shape), (1, 1), (0, 0), accum=other, bnred=(bn_x, bits, coef, 3, True),
                                accum_mask=bits)
             hip_ops._pending_bnred.clear()
-        row.append("%s %.3f" % (NAMES[a], timeit(f) * 1e3))
+        row.append("%s %.3f" % (NAMES.get(a, "128 x 64 tiles"), timeit(f) * 1e3))
+    C.igemm_set_lean(-1)
     print("%2dx%-2d dy[%4d] -> dx[%4d]: " % (H, H, Cout, Cin) + " | ".join(row), flush=True)
 C.igemm_set_lean_ablate(0)

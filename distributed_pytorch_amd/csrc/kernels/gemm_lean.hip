@@ -53,7 +53,7 @@ template <> struct LeanMma<f16_t> {
 };
 
 int g_lean_abl = 0;     // debug ablation of the plain variant (scratch/lean_ablate.py)
-int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 force 128-byte K tiles
+int g_lean_mode = -1;    // -1 automatic, 0 never, 1 force 64-byte K tiles, 2 force 128-byte K tiles, 3 force 128 x 64 tiles
 
 // BN: output channels per workgroup (128 | 64), BKB: bytes of K per staged row and K tile (64 | 128).
 // 256 threads = 2 (pixel) x 2 (channel) waves, 128 pixel rows per workgroup.
@@ -755,7 +755,7 @@ void launch_lean_tiles(const IgemmParams& p, bool strided, hipStream_t stream) {
   // A 256 x 256 tile (8 waves of 128 x 64, half the staged bytes per MFMA) in this same loop structure measured
   // +3 .. 15 % on the deep layers and 896 vs 822 TFLOP/s on a 200k x 2048 x 2048 GEMM
   // (profiles/r2/lean_gemm_256x256_tile.txt): not worth a second set of epilogues; the structure, not the tile, caps it.
-  const bool wide = p.N % 128 == 0;
+  const bool wide = p.N % 128 == 0 && g_lean_mode != 3;      // (mode 3: tuning, 64-channel tiles everywhere)
   const long tiles = (long)ceil_div(p.M, 128) * (p.N / (wide ? 128 : 64));
   // 128-byte K tiles (half the barriers) for long reductions and launches that barely fill the chip, as in
   // igemm.hip's choose_cfg(); 64-byte K tiles (more workgroups per CU) otherwise
