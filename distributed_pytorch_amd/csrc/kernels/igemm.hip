@@ -138,14 +138,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
   for (int j = 0; j < VECO; ++j) bmu[j] = bis[j] = bsc[j] = bsh[j] = 0.f;
   if constexpr (BNB) {
     if (!bn_fold) {
+      // coef[4][stats_ld]: stats_ld = all channels of the BN (== N for a dense launch).  BNB launches have whole chunks
+      // (N % VECO == 0): 16-byte loads -- per-element selects made these 32 separate dword loads per thread
+      const long c = gofs + (ncol + VECO <= p.N ? ncol : 0);
+      const bool recompute = (p.bn_relu & 3) == 2;
 #pragma unroll
-      for (int j = 0; j < VECO; ++j) {
-        // coef[4][stats_ld]: stats_ld = all channels of the BN (== N for a dense launch)
-        const long c = gofs + (ncol + j < p.N ? ncol + j : 0);
-        bmu[j] = p.bn_coef[c];
-        bis[j] = p.bn_coef[p.stats_ld + c];
-        bsc[j] = p.bn_coef[2 * (long)p.stats_ld + c];
-        bsh[j] = p.bn_coef[3 * (long)p.stats_ld + c];
+      for (int q = 0; q < VECO / 4; ++q) {
+        const float4 m4 = reinterpret_cast<const float4*>(p.bn_coef + c)[q];
+        const float4 i4 = reinterpret_cast<const float4*>(p.bn_coef + p.stats_ld + c)[q];
+        bmu[4 * q] = m4.x; bmu[4 * q + 1] = m4.y; bmu[4 * q + 2] = m4.z; bmu[4 * q + 3] = m4.w;
+        bis[4 * q] = i4.x; bis[4 * q + 1] = i4.y; bis[4 * q + 2] = i4.z; bis[4 * q + 3] = i4.w;
+        if (recompute) {
+          const float4 s4 = reinterpret_cast<const float4*>(p.bn_coef + 2 * (long)p.stats_ld + c)[q];
+          const float4 h4 = reinterpret_cast<const float4*>(p.bn_coef + 3 * (long)p.stats_ld + c)[q];
+          bsc[4 * q] = s4.x; bsc[4 * q + 1] = s4.y; bsc[4 * q + 2] = s4.z; bsc[4 * q + 3] = s4.w;
+          bsh[4 * q] = h4.x; bsh[4 * q + 1] = h4.y; bsh[4 * q + 2] = h4.z; bsh[4 * q + 3] = h4.w;
+        }
       }
     }
   }
@@ -158,8 +166,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
       const int cch = wn * WTN + a * 32 + 8 * g + 4 * lh;
       float bs[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.bias != nullptr) {
+        if (n0 + cch + 3 < p.N && ((gofs + n0) & 3) == 0) {       // one 16-byte load (cch is a multiple of 4)
+          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + gofs + n0 + cch);
+          bs[0] = b4.x; bs[1] = b4.y; bs[2] = b4.z; bs[3] = b4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] = (n0 + cch + j < p.N) ? p.bias[gofs + n0 + cch + j] : 0.f;
+          for (int j = 0; j < 4; ++j) bs[j] = (n0 + cch + j < p.N) ? p.bias[gofs + n0 + cch + j] : 0.f;
+        }
       }
 #pragma unroll
       for (int b = 0; b < MI; ++b) {
