@@ -507,10 +507,16 @@ __global__ __launch_bounds__(512, 1) void conv8_kernel(const IgemmParams p, cons
       for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + nq * 32 + 8 * gq + 4 * lh + j;
-            bv[nq][gq][j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+          {
+            // (one 16-byte load where the four channels exist: per-element selects made these 32 dword loads per thread)
+            const int n = n0 + wc * 64 + nq * 32 + 8 * gq + 4 * lh;
+            if (p.bias != nullptr && n + 3 < p.N) {
+              const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+              bv[nq][gq][0] = b4.x; bv[nq][gq][1] = b4.y; bv[nq][gq][2] = b4.z; bv[nq][gq][3] = b4.w;
+            } else {
+          #pragma unroll
+              for (int j = 0; j < 4; ++j) bv[nq][gq][j] = (p.bias != nullptr && n + j < p.N) ? p.bias[n + j] : 0.f;
+            }
           }
     }
     const bool relu = EPI == kEpiPlain && (p.flags & kIgemmRelu);
