@@ -448,6 +448,9 @@ PYBIND11_MODULE(_C, m) {
     shuffle_pair_launch(ptr<const void>(a), ptr<const void>(b), ptr<void>(o0), ptr<void>(o1), rows, bf, P, backward, dtype,
                         st(s));
   });
+  m.def("subsample", [](uintptr_t src, uintptr_t dst, long NB, int IH, int IW, long row_bytes, int stride, uintptr_t s) {
+    subsample_launch(ptr<const void>(src), ptr<void>(dst), NB, IH, IW, row_bytes, stride, st(s));
+  });
   m.def("copy_rows", [](uintptr_t src, long ld_src, uintptr_t dst, long ld_dst, long rows, long row_bytes, uintptr_t s) {
     copy_rows_launch(ptr<const void>(src), ld_src, ptr<void>(dst), ld_dst, rows, row_bytes, st(s));
   });

@@ -354,6 +354,22 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint4* __restrict_
   }
 }
 
+// dst[n][oy][ox][:] = src[n][oy * s][ox * s][:] for NHWC tensors, 16 bytes per lane: the pixels a stride-s 1x1 convolution reads,
+// gathered once for the dense GEMMs of the folded downsample branch (ATen's strided copy ran at a third of the bandwidth)
+__global__ __launch_bounds__(256) void subsample_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long total,
+                                                        int OH, int OW, int IH, int IW, int s, int chunks) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long pix = i / chunks;
+    const int c = (int)(i - pix * chunks);
+    const long t = pix / OW;
+    const int ox = (int)(pix - t * OW);
+    const long n = t / OH;
+    const int oy = (int)(t - n * OH);
+    dst[i] = src[((n * IH + (long)oy * s) * IW + (long)ox * s) * chunks + c];
+  }
+}
+
 // ShuffleNetV2 channel shuffle (groups = 2) fused with the channel split that always follows it.  A stage's activation
 // lives as a PAIR of tensors (left, right), each [rows][P] with `bf` real channels and P - bf zero pad channels (P = bf
 // rounded up to 16-byte vectors: ShuffleNetV2 x1.0 / x2.0 have 58 / 122-channel halves).
@@ -538,6 +554,17 @@ void copy_rows_launch(const void* src, long ld_src_bytes, void* dst, long ld_dst
   const int chunks = (int)(row_bytes / 16);
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * chunks)), dim3(256), 0, s, (const uint4*)src,
                      ld_src_bytes / 16, (uint4*)dst, ld_dst_bytes / 16, rows, chunks);
+  DPA_CHECK_HIP(hipGetLastError());
+}
+
+void subsample_launch(const void* src, void* dst, long NB, int IH, int IW, long row_bytes, int s_, hipStream_t s) {
+  if (row_bytes % 16 || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16) || s_ < 1)
+    throw std::invalid_argument("subsample: pixels must be multiples of 16 bytes");
+  const int OH = (IH + s_ - 1) / s_, OW = (IW + s_ - 1) / s_, chunks = (int)(row_bytes / 16);
+  const long total = NB * OH * OW * chunks;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(subsample_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, total, OH, OW,
+                     IH, IW, s_, chunks);
   DPA_CHECK_HIP(hipGetLastError());
 }
 

@@ -309,6 +309,8 @@ void axpby_launch(const void* x, int x_dtype, float* y, long n, float alpha, flo
 void fill_launch(void* p, long nbytes, int value, hipStream_t s);
 // ShuffleNetV2: (o0, o1) = split(channel_shuffle(cat(a, b), groups = 2)) on [rows][P] tensors with bf real channels
 // (the rest zero padding); backward != 0: the inverse permutation (a, b = gradients of o0, o1 -> gradients of a, b)
+// NHWC pixels (n, oy * s, ox * s) gathered into a dense tensor
+void subsample_launch(const void* src, void* dst, long NB, int IH, int IW, long row_bytes, int s_, hipStream_t s);
 void shuffle_pair_launch(const void* a, const void* b, void* o0, void* o1, long rows, int bf, int P, int backward,
                          int dtype, hipStream_t s);
 // strided 2-D copy in 16-byte chunks: channel concat / split of NHWC activations

@@ -417,6 +417,18 @@ def _grad_into(param, fill):
     param.grad = g if param.grad is None else param.grad + g
 
 
+def _subsample(x: torch.Tensor, s: int) -> torch.Tensor:
+    """x[:, ::s, ::s, :] as a dense tensor (the pixels a stride-s 1x1 convolution reads)."""
+    if s == 1:
+        return x
+    NB, IH, IW, Cc = x.shape
+    if not x.is_contiguous() or (Cc * x.element_size()) % 16:
+        return x[:, ::s, ::s, :].contiguous()
+    y = torch.empty((NB, (IH + s - 1) // s, (IW + s - 1) // s, Cc), dtype=x.dtype, device=x.device)
+    C().subsample(x.data_ptr(), y.data_ptr(), NB, IH, IW, Cc * x.element_size(), s, _stream())
+    return y
+
+
 def _conv_bn_fold_backward(ctx, fent, pre=None):
     """Backward of (1x1 convolution -> training BatchNorm [+ residual + ReLU]) without the BatchNorm-backward apply pass:
     see csrc/kernels/bnfold.hip for the algebra.  `fent` comes from _BNFn.backward, `ctx` is the convolution's.
@@ -428,7 +440,7 @@ def _conv_bn_fold_backward(ctx, fent, pre=None):
     (sh, sw) = ctx.geom[0]
     if (sh, sw) != (1, 1):
         # strided 1x1 branch: everything below is a dense problem on the pixels the convolution really read
-        a = pre[3] if (pre is not None and len(pre) > 3) else a[:, ::sh, ::sw, :].contiguous()
+        a = pre[3] if (pre is not None and len(pre) > 3) else (_subsample(a, sh) if sh == sw else a[:, ::sh, ::sw, :].contiguous())
     NB, IH, IW, Cx = a.shape
     N = weight.shape[0]
     M = NB * IH * IW
@@ -661,7 +673,7 @@ class _ConvBnCatReluFn(torch.autograd.Function):
         M = NB * IH * IW
         dev, dt, st = a.device, a.dtype, _stream()
         one = _tap_table(dev, ((0, 0, 0),))
-        xs = x if stride == 1 else x[:, ::stride, ::stride, :].contiguous()
+        xs = _subsample(x, stride)
         Cd = xs.shape[-1]
 
         def stats(inp, Cc, w, g, b, rm, rv, nbt, mom, eps, cs=None):

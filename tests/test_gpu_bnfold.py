@@ -214,3 +214,9 @@ def test_bn_apply_with_column_sums(M, Cc, dtype):
     assert torch.equal(y1, y0)
     assert torch.equal(part[:, 1], torch.zeros_like(part[:, 1]))
     assert_close(part[:, 0].double().sum(0).float(), y0.double().sum(0).float(), torch.float32, scale=20, what="column sums")
+
+
+@pytest.mark.parametrize("shape,s", [((3, 14, 18, 64), 2), ((2, 7, 9, 128), 2), ((2, 8, 8, 32), 4)])
+def test_subsample_gather(shape, s):
+    x = torch.randn(*shape, device=DEV).to(torch.bfloat16)
+    assert torch.equal(hip_ops._subsample(x, s), x[:, ::s, ::s, :].contiguous())
