@@ -122,8 +122,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16_t (&
     for (int i = 0; i < E_IT; ++i) {
       if (i < first || i >= last) continue;
       const uint32_t m = m0 + (tid + i * 256) / CE;
-      const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0, no scatter
-      const size_t goff = ok ? ((size_t)m * p.ldc + gofs + ncol) * sizeof(TOut) : 0;   // grouped: this group's slice
+      const bool ok = m < (uint32_t)p.M && ncol + VECO <= p.N;       // BNB launches: N % VECO == 0
+      size_t orow = m;
+      if (p.flags & kIgemmScatter) {       // a parity class of a strided data gradient: the row this tile row is stored to
+        const uint32_t n = fdiv(ok ? m : 0u, p.div_ohow);
+        const uint32_t rem = (ok ? m : 0u) - n * p.div_ohow.d;
+        const uint32_t oy = fdiv(rem, p.div_ow);
+        const uint32_t ox = rem - oy * p.div_ow.d;
+        orow = ((size_t)n * p.OHF + oy * p.OSY + p.OY0) * p.OWF + ox * p.OSX + p.OX0;
+      }
+      const size_t goff = ok ? (orow * p.ldc + gofs + ncol) * sizeof(TOut) : 0;   // grouped: this group's slice
       if (bn_fold) px[i] = make_uint4(0u, 0u, 0u, 0u);
       else px[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_x) + goff);
       if (p.bn_relu == 1) pz[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.bn_z) + goff);

@@ -836,7 +836,10 @@ class _ConvFn(torch.autograd.Function):
         ctx.bnsrc = None
         if bnsrc is not None:
             bnsrc.uses += 1
-            if _FUSE_BN_BWD and x is x_in and (sh, sw) == (1, 1) and Cx == Cw and x.dtype != torch.float32 \
+            strided_ok = _FUSE_BN_BWD_STRIDED and (sh, sw) == (2, 2) and (R, S) == (3, 3) and (ph, pw) == (1, 1) \
+                and IH % 2 == 0 and IW % 2 == 0 and bnsrc.mode != 1 and not bnsrc.fold
+            if _FUSE_BN_BWD and x is x_in and ((sh, sw) == (1, 1) or strided_ok) and Cx == Cw \
+                    and x.dtype != torch.float32 \
                     and bnsrc.x.shape == x.shape and bnsrc.x.dtype == x.dtype \
                     and _FUSE_BN_BWD_MIN <= x.numel() * x.element_size() <= _FUSE_BN_BWD_MAX:
                 ctx.bnsrc = bnsrc
@@ -984,6 +987,10 @@ _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") == "1"
 # group's reduction is only 9 * 64 channels deep, too short to hide the epilogue's extra operand loads: resnext50_32x4d
 # 8,765 -> 8,675 img/s, resnext101_32x8d 3,019 -> 2,994 img/s with it on (profiles/r2/group_bnb_ab.txt)
 _FUSE_BN_BWD_GROUPED = os.environ.get("DPA_FUSE_BN_BWD_GROUPED", "0") == "1"
+# ... also in the parity-class launches of a STRIDED data gradient (3x3 stride 2: four launches, one shared slab).
+# Implemented and tested, off: the twelve launches of ResNet-50 lose more (general-kernel epilogue) than the three
+# stand-alone reductions cost -- 65.5 vs 65.2 ms/step (profiles/r3_notes.md)
+_FUSE_BN_BWD_STRIDED = os.environ.get("DPA_FUSE_BN_BWD_STRIDED", "0") == "1"
 _FUSE_BN_BWD_MIN = int(float(os.environ.get("DPA_FUSE_BN_BWD_MIN_MB", "0")) * 2 ** 20)
 _FUSE_BN_BWD_MAX = int(float(os.environ.get("DPA_FUSE_BN_BWD_MAX_MB", "1e9")) * 2 ** 20)
 # data_ptr of a freshly produced data gradient -> (partial slab, data_ptr of the BN input it was reduced
@@ -1091,6 +1098,21 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
     else:
         dx = (torch.zeros if need_zero else torch.empty)((NB, IH, IW, Cx), dtype=dy.dtype, device=dy.device)
     row3 = S == 3 and (sh, sw) == (1, 1) and pw == 1 and OW == IW
+    # fused BN-backward sums: one launch that covers every input pixel once, or -- strided convolutions -- parity classes
+    # that do so together (every class non-empty): each class leaves its rows in one shared slab
+    fuse_bnb = bnred is not None and K % 32 == 0 and not need_zero and \
+        (len(classes) == 1 or (_FUSE_BN_BWD_STRIDED and all(len(t) > 0 for _, _, t in classes)))
+    slab_all, slab_row = None, 0
+    if fuse_bnb and len(classes) > 1:
+        total = 0
+        for py, px, taps in classes:
+            SH, SW = (IH - py + sh - 1) // sh, (IW - px + sw - 1) // sw
+            if SH <= 0 or SW <= 0:
+                fuse_bnb = False
+                break
+            total += C().igemm_stats_rows(NB * SH * SW, Cx, K, len(taps), _dt(dy), _dt(dy))
+        if fuse_bnb:
+            slab_all = torch.empty((total, 2, Cx), dtype=torch.float32, device=dy.device)
     for py, px, taps in classes:
         if not taps:
             continue
@@ -1102,9 +1124,13 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
         tt = _tap_table(dy.device, taps)
         scatter = None if (sh == 1 and sw == 1) else (IH, IW, sh, sw, py, px)
         slab = None
-        if bnred is not None and scatter is None and len(classes) == 1 and K % 32 == 0:
+        if fuse_bnb:
             rows = C().igemm_stats_rows(NB * SH * SW, Cx, K, len(taps), _dt(dy), _dt(dy))
-            slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
+            if slab_all is not None:
+                slab = slab_all[slab_row:slab_row + rows]
+                slab_row += rows
+            else:
+                slab = torch.empty((rows, 2, Cx), dtype=torch.float32, device=dy.device)
         # dx is the gradient of a ReLU output (xmask): store it through that ReLU's mask (filter-row launches)
         xm = xmask if (xmask is not None and slab is None and row3 and scatter is None and len(classes) == 1
                        and not need_zero and rstride is None and Cx % _vec(dy.dtype) == 0
@@ -1113,7 +1139,8 @@ def conv_dgrad(dy, weight, xshape, stride, padding, accum=None, bnred=None, accu
                SH, SW, scatter=scatter, dtype=dy.dtype, out_dtype=dy.dtype, accum=accum,
                bnred=bnred if slab is not None else None, row3=row3, accum_mask=accum_mask, rstride=rstride, xmask=xm)
         if slab is not None:
-            _pending_bnred[dx.data_ptr()] = (slab, bnred[0].data_ptr(), dx._version, len(bnred) > 4 and bool(bnred[4]))
+            _pending_bnred[dx.data_ptr()] = (slab_all if slab_all is not None else slab, bnred[0].data_ptr(), dx._version,
+                                             len(bnred) > 4 and bool(bnred[4]))
         if xm is not None:
             _premasked[dx.data_ptr()] = (dx._version, _generation, xm.data_ptr())
     return dx

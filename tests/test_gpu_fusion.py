@@ -244,3 +244,45 @@ def test_fused_attention(case, dtype):
     assert_close(qkv.grad, qr.grad, cmp, what="dqkv", scale=4)
     if has_bias:
         assert_close(rel.grad, rr.grad, cmp, what="dbias", scale=4)
+
+
+@pytest.mark.parametrize("bn_mode", [0, 2, 3])
+@pytest.mark.parametrize("shape", [(3, 12, 16, 64, 128), (2, 14, 14, 128, 128)])
+def test_strided_data_gradient_reduces_bn_backward_sums_in_its_parity_classes(shape, bn_mode):
+    """3x3 stride-2 data gradient = four parity-class launches that together write every input pixel once: each leaves its
+    BN-backward partial sums in one shared slab (same stored gradient as without the fusion, sums equal to the stand-alone
+    reducer's on that gradient)."""
+    N, H, W, Cin, Cout = shape
+    C = hip_ops.C()
+    dt = torch.bfloat16
+    torch.manual_seed(21)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV) / (Cin * 9) ** 0.5).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, H // 2, W // 2, Cout, device=DEV).to(dt)
+    bn_x = (torch.randn(N, H, W, Cin, device=DEV) * 1.5 + 0.3).to(dt)
+    coef = torch.stack([torch.randn(Cin, device=DEV) * 0.1, torch.rand(Cin, device=DEV) + 0.5,
+                        torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.2]).contiguous()
+    z = None
+    if bn_mode == 3:
+        zz = torch.randn(N, H, W, Cin, device=DEV)
+        bits = (zz.view(-1, 8) > 0).to(torch.uint8) << torch.arange(8, device=DEV, dtype=torch.uint8)
+        z = bits.sum(1).to(torch.uint8).contiguous()
+    hip_ops._pending_bnred.clear()
+    old = hip_ops._FUSE_BN_BWD_STRIDED
+    hip_ops._FUSE_BN_BWD_STRIDED = True          # (off by default: measured a small loss on ResNet-50)
+    try:
+        dx = hip_ops.conv_dgrad(dy, w, (N, H, W, Cin), (2, 2), (1, 1), bnred=(bn_x, z, coef, bn_mode))
+    finally:
+        hip_ops._FUSE_BN_BWD_STRIDED = old
+    ent = hip_ops._pending_bnred.pop(dx.data_ptr(), None)
+    assert ent is not None, "the strided launches did not take the fused reduction"
+    ref = hip_ops.conv_dgrad(dy, w, (N, H, W, Cin), (2, 2), (1, 1))
+    assert torch.equal(dx, ref)
+    M = N * H * W
+    nblk = C.bn_partial_rows(M, Cin)
+    part = torch.empty(nblk, 2, Cin, device=DEV)
+    C.bn_bwd_reduce(dx.data_ptr(), bn_x.data_ptr(), z.data_ptr() if z is not None else 0, M, Cin, hip_ops._dt(dx),
+                    coef[0].data_ptr(), coef[1].data_ptr(), bn_mode, coef[2].data_ptr(), coef[3].data_ptr(),
+                    part.data_ptr(), nblk, torch.cuda.current_stream().cuda_stream)
+    got, want = ent[0].sum(0), part.sum(0)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 1e-4 * scale, (got - want).abs().max().item() / scale
