@@ -129,6 +129,26 @@ PYBIND11_MODULE(_C, m) {
   });
   m.def("wgrad_row3_set_mode", &wgrad_row3_set_mode);
   m.def("wgrad_row3_set_variant", &wgrad_row3_set_variant);
+  m.def("wgrad8_set_mode", &wgrad8_set_mode);
+  m.def("wgrad8_covers", &wgrad8_covers);
+  m.def("wgrad8_splits", [](long M, int N, int N2, int Cc, int dtype) -> py::tuple {
+    int pps = 0;
+    if (!wgrad8_covers(M, N, N2, Cc, dtype)) return py::make_tuple(0, 0);
+    const int s = wgrad8_choose_splits(M, N, N2, Cc, &pps);
+    return py::make_tuple(s, pps);
+  });
+  m.def("wgrad8", [](uintptr_t dY, uintptr_t X, uintptr_t slab, int M, int N, int Cc, int ldy, int ldx, int splits, int pps,
+                     int dtype, uintptr_t stream, uintptr_t dY2, int N2, int ldy2) {
+    WgradParams p;
+    p.dY = ptr<const void>(dY); p.X = ptr<const void>(X); p.slab = ptr<float>(slab); p.taps = nullptr;
+    p.dY2 = ptr<const void>(dY2); p.N2 = N2; p.ldy2 = ldy2;
+    p.M = M; p.N = N; p.Cred = Cc; p.ntaps = 1; p.Ktot = Cc; p.ldy = ldy; p.ldx = ldx;
+    p.IH = p.IW = 1; p.SY = p.SX = 1; p.splits = splits; p.pix_per_split = pps; p.taps_zero = 1;
+    p.div_ohow = make_fastdiv(1u); p.div_ow = make_fastdiv(1u);
+    wgrad8_launch(p, dtype, st(stream));
+  }, py::arg("dY"), py::arg("X"), py::arg("slab"), py::arg("M"), py::arg("N"), py::arg("C"), py::arg("ldy"), py::arg("ldx"),
+     py::arg("splits"), py::arg("pps"), py::arg("dtype"), py::arg("stream"), py::arg("dY2") = 0, py::arg("N2") = 0,
+     py::arg("ldy2") = 0);
   m.def("wgrad_force_config", &wgrad_force_config);
   m.def("wgrad_num_configs", &wgrad_num_configs);
   m.def("wgrad_set_target_blocks", &wgrad_set_target_blocks);

@@ -136,6 +136,15 @@ void wgrad_force_config(int cfg);   // tuning hook, -1 = automatic
 int wgrad_num_configs();
 void wgrad_set_target_blocks(int n);   // tuning hook: workgroups the pixel split aims for
 
+// ------------------------------------------------------------------------------ wgrad8.hip
+// Dense 1x1 weight gradient (+ second gradient operand) on the 256 x 256 LDS-DMA pipeline with transposed fragment
+// reads.  Same slab layout as wgrad_launch ([splits][N + N2][C]); the caller asks wgrad8_covers first and takes the
+// pixel split from wgrad8_choose_splits (multiples of 64 pixels, one workgroup per CU).
+bool wgrad8_covers(long M, int N, int N2, int C, int dtype);
+int wgrad8_choose_splits(long M, int N, int N2, int C, int* pix_per_split);
+void wgrad8_launch(const WgradParams& p, int dtype, hipStream_t stream);
+void wgrad8_set_mode(int mode);       // -1 automatic, 0 never, 1 whenever covered
+
 // ------------------------------------------------------------------------------ wgrad_row3.hip
 // Filter-row weight gradient (R x 3, stride 1, "same"): one staged activation row tile serves the three taps of a filter
 // row.  wgrad_row3_splits() == 0: not covered (image width > 64, fp32, channels not a multiple of 64): use wgrad_launch.

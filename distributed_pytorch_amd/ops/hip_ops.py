@@ -42,6 +42,7 @@ def C():
         _C.igemm_set_lean(int(os.environ.get("DPA_IGEMM_LEAN", "-1")))   # lean 1x1 GEMM: -1 auto, 0 off
         # convolutions on the 256 x 256 multi-phase pipeline (csrc/kernels/conv8.hip): -1 auto, 0 off, 1 / 2 forced
         _C.wgrad_row3_set_mode(int(os.environ.get("DPA_WGRAD_ROW3", "-1")))     # filter-row weight gradient: -1 auto, 0 off
+        _C.wgrad8_set_mode(int(os.environ.get("DPA_WGRAD8", "-1")))             # 256 x 256 dense 1x1 weight gradient
         _C.conv8_set_mode(int(os.environ.get("DPA_CONV8", "-1")))
         _C.conv8_set_min_k(int(os.environ.get("DPA_CONV8_MIN_K", "512")))
         _C.conv8_set_tail_split(int(os.environ.get("DPA_CONV8_TAIL", "4")))
@@ -390,14 +391,21 @@ def _wgrad_raw(dy2d_src, x_src, M, N, Cc, IH, IW, gram: bool = False, out_dtype=
     (x is staged once for both)."""
     ldy = N if ldy is None else ldy
     ldx = Cc if ldx is None else ldx
-    splits, pps = C().wgrad_choose_splits(M, N, Cc, _dt(dy2d_src))
     rows = N + (Cc if gram else 0)
-    slab = torch.empty((splits, rows, Cc), dtype=torch.float32, device=dy2d_src.device)
-    taps = _tap_table(dy2d_src.device, ((0, 0, 0),))
     st = _stream()
-    C().wgrad(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, N, Cc, 1, ldy, ldx, IH, IW,
-              1, 1, IH, IW, splits, pps, 1, _dt(dy2d_src), st, 1, 0, 0, 0, 0,
-              x_src.data_ptr() if gram else 0, Cc if gram else 0, ldx if gram else 0)
+    # deep layers: the 256 x 256 LDS-DMA pipeline (csrc/kernels/wgrad8.hip); 0 splits = not covered
+    splits, pps = C().wgrad8_splits(M, N, Cc if gram else 0, Cc, _dt(dy2d_src))
+    if splits > 0:
+        slab = torch.empty((splits, rows, Cc), dtype=torch.float32, device=dy2d_src.device)
+        C().wgrad8(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), M, N, Cc, ldy, ldx, splits, pps,
+                   _dt(dy2d_src), st, x_src.data_ptr() if gram else 0, Cc if gram else 0, ldx if gram else 0)
+    else:
+        splits, pps = C().wgrad_choose_splits(M, N, Cc, _dt(dy2d_src))
+        slab = torch.empty((splits, rows, Cc), dtype=torch.float32, device=dy2d_src.device)
+        taps = _tap_table(dy2d_src.device, ((0, 0, 0),))
+        C().wgrad(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, N, Cc, 1, ldy, ldx, IH, IW,
+                  1, 1, IH, IW, splits, pps, 1, _dt(dy2d_src), st, 1, 0, 0, 0, 0,
+                  x_src.data_ptr() if gram else 0, Cc if gram else 0, ldx if gram else 0)
     out = torch.empty((rows, Cc), dtype=out_dtype, device=dy2d_src.device)
     C().slab_reduce(slab.data_ptr(), splits, rows * Cc, out.data_ptr(), _dt(out_dtype), 0.0, st)
     return out
@@ -1159,10 +1167,18 @@ def conv_wgrad(dy, x, weight, stride, padding, axf=None):
     if S == 3 and (sh, sw) == (1, 1) and pw == 1 and (OH, OW) == (IH, IW) and axf is None and x.is_contiguous():
         # filter-row kernel: one staged activation row tile per filter ROW instead of per tap (csrc/kernels/wgrad_row3.hip)
         splits, rps = C().wgrad_row3_splits(NB, IH, IW, K, Cx, R, _dt(dy))
+    dense8 = 0
+    if R * S == 1 and (sh, sw) == (1, 1) and ph == 0 and pw == 0 and axf is None and x.is_contiguous() \
+            and dy.is_contiguous():
+        dense8, pps8 = C().wgrad8_splits(M, K, 0, Cx, _dt(dy))
     if splits > 0:
         slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
         C().wgrad_row3(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), NB, IH, IW, K, Cx, R, ph, K, Cx, splits, rps,
                        _dt(dy), st)
+    elif dense8 > 0:
+        splits = dense8
+        slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
+        C().wgrad8(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), M, K, Cx, K, Cx, splits, pps8, _dt(dy), st)
     else:
         splits, pps = C().wgrad_choose_splits(M, K, Ktot, _dt(dy))
         slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
