@@ -130,13 +130,13 @@ PYBIND11_MODULE(_C, m) {
   m.def("wgrad_row3_set_mode", &wgrad_row3_set_mode);
   m.def("wgrad_row3_set_variant", &wgrad_row3_set_variant);
   m.def("wgrad8_set_mode", &wgrad8_set_mode);
-  m.def("wgrad8_covers", &wgrad8_covers);
-  m.def("wgrad8_splits", [](long M, int N, int N2, int Cc, int dtype) -> py::tuple {
+  m.def("wgrad8_splits", [](long M, int N, int N2, int Cred, int dtype, int ntaps, bool gather) -> py::tuple {
     int pps = 0;
-    if (!wgrad8_covers(M, N, N2, Cc, dtype)) return py::make_tuple(0, 0);
-    const int s = wgrad8_choose_splits(M, N, N2, Cc, &pps);
+    if (!wgrad8_covers(M, N, N2, Cred, ntaps, gather, dtype)) return py::make_tuple(0, 0);
+    const int s = wgrad8_choose_splits(M, N, N2, ntaps * Cred, &pps);
     return py::make_tuple(s, pps);
-  });
+  }, py::arg("M"), py::arg("N"), py::arg("N2"), py::arg("Cred"), py::arg("dtype"), py::arg("ntaps") = 1,
+     py::arg("gather") = false);
   m.def("wgrad8", [](uintptr_t dY, uintptr_t X, uintptr_t slab, int M, int N, int Cc, int ldy, int ldx, int splits, int pps,
                      int dtype, uintptr_t stream, uintptr_t dY2, int N2, int ldy2) {
     WgradParams p;
@@ -161,7 +161,7 @@ PYBIND11_MODULE(_C, m) {
         [](uintptr_t dY, uintptr_t X, uintptr_t slab, uintptr_t taps, int M, int N, int Cred, int ntaps, int ldy,
            int ldx, int IH, int IW, int SY, int SX, int OH, int OW, int splits, int pps, int taps_zero, int dtype,
            uintptr_t stream, int groups, long y_gstride, long x_gstride, uintptr_t x_scale, uintptr_t x_shift,
-           uintptr_t dY2, int N2, int ldy2) {
+           uintptr_t dY2, int N2, int ldy2, int use8) {
           WgradParams p;
           p.dY2 = ptr<const void>(dY2); p.N2 = N2; p.ldy2 = ldy2;
           p.x_scale = ptr<const float>(x_scale);
@@ -177,13 +177,15 @@ PYBIND11_MODULE(_C, m) {
           p.splits = splits; p.pix_per_split = pps;
           p.div_ohow = make_fastdiv((uint32_t)(OH * OW));
           p.div_ow = make_fastdiv((uint32_t)OW);
-          wgrad_launch(p, dtype, st(stream));
+          if (use8) wgrad8_launch(p, dtype, st(stream));      // splits from wgrad8_splits
+          else wgrad_launch(p, dtype, st(stream));
         },
         py::arg("dY"), py::arg("X"), py::arg("slab"), py::arg("taps"), py::arg("M"), py::arg("N"), py::arg("Cred"),
         py::arg("ntaps"), py::arg("ldy"), py::arg("ldx"), py::arg("IH"), py::arg("IW"), py::arg("SY"), py::arg("SX"),
         py::arg("OH"), py::arg("OW"), py::arg("splits"), py::arg("pps"), py::arg("taps_zero"), py::arg("dtype"),
         py::arg("stream"), py::arg("groups") = 1, py::arg("y_gstride") = 0, py::arg("x_gstride") = 0,
-        py::arg("x_scale") = 0, py::arg("x_shift") = 0, py::arg("dY2") = 0, py::arg("N2") = 0, py::arg("ldy2") = 0);
+        py::arg("x_scale") = 0, py::arg("x_shift") = 0, py::arg("dY2") = 0, py::arg("N2") = 0, py::arg("ldy2") = 0,
+        py::arg("use8") = 0);
   m.def("slab_reduce", [](uintptr_t slab, int splits, long n, uintptr_t out, int out_dtype, float beta, uintptr_t s) {
     slab_reduce_launch(ptr<const float>(slab), splits, n, ptr<void>(out), out_dtype, beta, st(s));
   });

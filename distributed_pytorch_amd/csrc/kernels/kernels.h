@@ -137,11 +137,11 @@ int wgrad_num_configs();
 void wgrad_set_target_blocks(int n);   // tuning hook: workgroups the pixel split aims for
 
 // ------------------------------------------------------------------------------ wgrad8.hip
-// Dense 1x1 weight gradient (+ second gradient operand) on the 256 x 256 LDS-DMA pipeline with transposed fragment
-// reads.  Same slab layout as wgrad_launch ([splits][N + N2][C]); the caller asks wgrad8_covers first and takes the
+// Weight gradient of wide layers (dense 1x1 + second gradient operand, or gathered taps with Cred % 128 == 0) on the
+// 256 x 256 LDS-DMA pipeline with transposed fragment reads.  Same slab layout as wgrad_launch ([splits][N + N2][C]); the caller asks wgrad8_covers first and takes the
 // pixel split from wgrad8_choose_splits (multiples of 64 pixels, one workgroup per CU).
-bool wgrad8_covers(long M, int N, int N2, int C, int dtype);
-int wgrad8_choose_splits(long M, int N, int N2, int C, int* pix_per_split);
+bool wgrad8_covers(long M, int N, int N2, int Cred, int ntaps, bool gather, int dtype);
+int wgrad8_choose_splits(long M, int N, int N2, int Ktot, int* pix_per_split);
 void wgrad8_launch(const WgradParams& p, int dtype, hipStream_t stream);
 void wgrad8_set_mode(int mode);       // -1 automatic, 0 never, 1 whenever covered
 

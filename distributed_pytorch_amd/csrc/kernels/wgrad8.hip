@@ -1,4 +1,4 @@
-// Weight gradient of dense 1x1 problems on the 256 x 256 multi-phase pipeline (gemm8.hip's structure):
+// Weight gradient of wide layers on the 256 x 256 multi-phase pipeline (gemm8.hip's structure); dense 1x1 problems:
 //
 //     dW[n][c] = sum_m dY[m][n] * X[m][c]          (rows N .. N + N2 - 1: dY2^T X, the Gram matrix of the BN fold)
 //
@@ -17,6 +17,9 @@
 // LDS layout of a half-tile: [pixel 0..63][256 bytes], the 64-byte quarter q (32 channels) of pixel row k stored at
 // quarter q ^ (k & 3): the source address is permuted, the DMA writes linearly.  A transposed read touches, per half
 // wave, 4 consecutive pixel rows x 64 bytes of ONE logical quarter -> 4 distinct physical quarters = all 64 banks once.
+//
+// Convolutions with taps (3x3, strided 1x1, ...): dW[n][t*Cred + c] = sum_m dY[m][n] * X[pix(m) + tap_t][c], template
+// parameter GATHER below.
 //
 // The pixel range is split over workgroups as in wgrad.hip: fp32 partial slabs [split][N + N2][C], folded in a fixed
 // order by slab_reduce_kernel.  Pixels past the end of a split and channels past N / C read a zero page.
@@ -63,7 +66,10 @@ template <> struct MmaW8<f16_t> {
   }
 };
 
-template <typename T>
+// GATHER: X is an NHWC image and column j = tap * Cred + c of the gradient reads pixel (oy * SY + dy_tap, ox * SX + dx_tap)
+// (Cred a multiple of 128: a 128-column half-tile lies inside one tap).  The (image, row, column) of the two pixel rows a
+// lane stages advance incrementally from K tile to K tile; out-of-image taps read the zero page.
+template <typename T, bool GATHER>
 __global__ __launch_bounds__(512, 1) void wgrad8_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -107,9 +113,48 @@ __global__ __launch_bounds__(512, 1) void wgrad8_kernel(const WgradParams p) {
       const bool ok = col < (isY ? Nloc : p.Ktot);
       const char* base = reinterpret_cast<const char*>(isY ? (second ? p.dY2 : p.dY) : p.X);
       const long ld = isY ? ldyl : p.ldx;
+      if (GATHER && !isY) {         // per-tap addressing below
+        src[h][i] = zero;
+        step[h][i] = 0;
+        continue;
+      }
       src[h][i] = ok ? base + (((long)m_begin + pix) * ld + col) * (long)sizeof(T) : zero;
       step[h][i] = ok ? (int)(64 * ld * (long)sizeof(T)) : 0;
     }
+  // GATHER state: the tap of each X half-tile (workgroup-uniform), the lane's column inside it, and the coordinates of
+  // the lane's two pixel rows in the K tile that X0 stages next (X1 of the same K tile follows and advances them)
+  int tap_dy[2] = {0, 0}, tap_dx[2] = {0, 0}, colb[2] = {0, 0};
+  bool colok[2] = {false, false};
+  int gn[2] = {0, 0}, goy[2] = {0, 0}, gox[2] = {0, 0};
+  int OHg = 1, OWg = 1, step_n = 0, step_oy = 0, step_ox = 0;
+  if constexpr (GATHER) {
+    const int pc = lane & 15;
+    const int lc = ((((pc >> 2) ^ (lane >> 4))) << 2) | (pc & 3);     // pix & 3 == lane >> 4 for both instructions
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col0 = j0 + h * 128;
+      const int t = min(col0, p.Ktot - 1) / p.Cred;
+      tap_dy[h] = p.taps[3 * t + 0];
+      tap_dx[h] = p.taps[3 * t + 1];
+      colb[h] = (col0 - t * p.Cred + lc * 8) * (int)sizeof(T);
+      colok[h] = col0 + lc * 8 < p.Ktot;
+    }
+    OWg = (int)p.div_ow.d;
+    OHg = (int)(p.div_ohow.d / p.div_ow.d);
+    step_n = 64 / (OHg * OWg);
+    const int rem = 64 - step_n * OHg * OWg;
+    step_oy = rem / OWg;
+    step_ox = rem - step_oy * OWg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t m = (uint32_t)(m_begin + pixl[i]);
+      const uint32_t n = fdiv(m, p.div_ohow);
+      const uint32_t r = m - n * p.div_ohow.d;
+      const uint32_t oy = fdiv(r, p.div_ow);
+      gn[i] = (int)n; goy[i] = (int)oy; gox[i] = (int)(r - oy * p.div_ow.d);
+    }
+  }
+  const long ldxb = (long)p.ldx * (long)sizeof(T);
   // request half-tile g (kind g & 3 of K tile g >> 2) into slot g & 7
   auto stage = [&](int g, auto kind_c) {
     constexpr int h = decltype(kind_c)::value;
@@ -117,9 +162,23 @@ __global__ __launch_bounds__(512, 1) void wgrad8_kernel(const WgradParams p) {
     const int lim = len - (g >> 2) * 64;            // pixel rows of that K tile inside the split
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const char* s = pixl[i] < lim ? src[h][i] : zero;
+      const char* s;
+      if constexpr (GATHER && h < 2) {
+        const int iy = goy[i] * p.SY + tap_dy[h], ix = gox[i] * p.SX + tap_dx[h];
+        const bool ok = pixl[i] < lim && colok[h] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int pixoff = (gn[i] * p.IH + iy) * p.IW + ix;
+        s = ok ? reinterpret_cast<const char*>(p.X) + (long)pixoff * ldxb + colb[h] : zero;
+        if constexpr (h == 1) {     // both X half-tiles of this K tile are requested: on to the next 64 pixels
+          int ox = gox[i] + step_ox, oy = goy[i] + step_oy, n = gn[i] + step_n;
+          if (ox >= OWg) { ox -= OWg; ++oy; }
+          if (oy >= OHg) { oy -= OHg; ++n; }
+          gox[i] = ox; goy[i] = oy; gn[i] = n;
+        }
+      } else {
+        s = pixl[i] < lim ? src[h][i] : zero;
+        src[h][i] += step[h][i];
+      }
       __builtin_amdgcn_global_load_lds((gbl_void_ptr_w8)s, (lds_void_ptr_w8)(dst + i * 1024), 16, 0, 0);
-      src[h][i] += step[h][i];
     }
   };
   constexpr std::integral_constant<int, 0> kX0{};
@@ -273,24 +332,27 @@ int g_wgrad8_mode = -1;   // -1 automatic, 0 never, 1 whenever covered
 
 void wgrad8_set_mode(int mode) { g_wgrad8_mode = mode; }
 
-// Covered: dense 16-bit 1x1 problem (the caller vouches for "dense 1x1": one (0, 0) tap, stride 1, no groups, no
-// apply-on-load) with 16-byte aligned rows.  Automatic: both sides of the gradient at least 256 wide and enough pixels
-// per workgroup to amortise the pipeline fill.
-bool wgrad8_covers(long M, int N, int N2, int C, int dtype) {
-  if (g_wgrad8_mode == 0 || dtype == kF32) return false;
-  if (N % 8 != 0 || N2 % 8 != 0 || C % 8 != 0 || M <= 0 || M >= (1l << 31)) return false;
+// Covered: 16-bit problems without groups / apply-on-load, 16-byte aligned rows; `gather` false is the DENSE case (one
+// (0, 0) tap, stride 1: the caller vouches for it), otherwise the gather variant, which needs Cred % 128 == 0 and no
+// second operand.  Automatic: both sides of the gradient at least 256 wide and enough pixels per workgroup to amortise
+// the pipeline fill.
+bool wgrad8_covers(long M, int N, int N2, int Cred, int ntaps, bool gather, int dtype) {
+  if (g_wgrad8_mode == 0 || dtype == kF32 || ntaps < 1 || (!gather && ntaps != 1)) return false;
+  if (N % 8 != 0 || N2 % 8 != 0 || Cred % 8 != 0 || M <= 0 || M >= (1l << 31)) return false;
+  if (gather && (Cred % 128 != 0 || N2 != 0)) return false;
   if (g_wgrad8_mode == 1) return true;
-  const long tiles = (long)(ceil_div(N, 256) + ceil_div(N2, 256)) * ceil_div(C, 256);
-  return N >= 256 && C >= 256 && tiles <= 128 && M >= tiles * 8 * 64;
+  const long Ktot = (long)ntaps * Cred;
+  const long tiles = (long)(ceil_div(N, 256) + ceil_div(N2, 256)) * ceil_div(Ktot, 256);
+  return N >= 256 && Ktot >= 256 && tiles <= 128 && M >= tiles * 8 * 64;
 }
 
 // One workgroup per CU: tiles x splits <= 256 (a second round of workgroups would double the time), >= 8 K tiles each.
-int wgrad8_choose_splits(long M, int N, int N2, int C, int* pix_per_split) {
-  const long tiles = (long)(ceil_div(N, 256) + ceil_div(N2, 256)) * ceil_div(C, 256);
+int wgrad8_choose_splits(long M, int N, int N2, int Ktot, int* pix_per_split) {
+  const long tiles = (long)(ceil_div(N, 256) + ceil_div(N2, 256)) * ceil_div(Ktot, 256);
   long splits = tiles >= 256 ? 1 : 256 / tiles;
   const long max_by_work = (M + 8l * 64 - 1) / (8l * 64);
   if (splits > max_by_work) splits = max_by_work;
-  const long out_elems = (long)(N + N2) * C;
+  const long out_elems = (long)(N + N2) * Ktot;
   const long max_by_slab = (64l << 20) / (out_elems * 4) + 1;
   if (splits > max_by_slab) splits = max_by_slab;
   if (splits < 1) splits = 1;
@@ -306,9 +368,17 @@ void wgrad8_launch(const WgradParams& p_in, int dtype, hipStream_t stream) {
   if (p.dY2 == nullptr) p.N2 = p.ldy2 = 0;
   if (p.M <= 0 || p.N <= 0 || p.Ktot <= 0) return;
   if (dtype == kF32) throw std::invalid_argument("wgrad8: 16-bit types only");
-  if (p.ntaps != 1 || !p.taps_zero || p.SY != 1 || p.SX != 1 || p.groups > 1 || p.x_scale != nullptr || p.Ktot != p.Cred)
-    throw std::invalid_argument("wgrad8: dense 1x1 problems only");
-  if (p.N % 8 || p.N2 % 8 || p.Ktot % 8 || p.ldy % 8 || p.ldx % 8 || p.ldy2 % 8 || p.ldy < p.N || p.ldx < p.Ktot ||
+  if (p.groups > 1 || p.x_scale != nullptr || p.ntaps < 1 || p.Ktot != p.ntaps * p.Cred)
+    throw std::invalid_argument("wgrad8: dense problems without groups / apply-on-load only");
+  const bool gather = !(p.ntaps == 1 && p.taps_zero && p.SY == 1 && p.SX == 1);
+  if (gather) {
+    const long OHOW = (long)p.div_ohow.d, OW = (long)p.div_ow.d;
+    if (p.Cred % 128 != 0 || p.N2 != 0 || p.taps == nullptr || OW <= 0 || OHOW <= 0 || OHOW % OW != 0 || p.M % OHOW != 0 ||
+        p.IH <= 0 || p.IW <= 0 || p.SY <= 0 || p.SX <= 0 || (p.M / OHOW) * p.IH * p.IW >= (1l << 31))
+      throw std::invalid_argument("wgrad8: the gather variant needs Cred % 128 == 0, no second operand, a tap table and "
+                                  "M = images * OH * OW");
+  }
+  if (p.N % 8 || p.N2 % 8 || p.Cred % 8 || p.ldy % 8 || p.ldx % 8 || p.ldy2 % 8 || p.ldy < p.N || p.ldx < p.Cred ||
       (p.N2 > 0 && p.ldy2 < p.N2))
     throw std::invalid_argument("wgrad8: channel counts / strides must be multiples of 16 bytes");
   if (((uintptr_t)p.dY | (uintptr_t)p.X | (uintptr_t)p.dY2) & 15)
@@ -321,16 +391,24 @@ void wgrad8_launch(const WgradParams& p_in, int dtype, hipStream_t stream) {
   const long blocks = (long)(ceil_div(p.N, 256) + ceil_div(p.N2, 256)) * ceil_div(p.Ktot, 256) * p.splits;
   static bool attr_done = false;
   if (!attr_done) {
-    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel<bf16_t>),
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel<bf16_t, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRingW));
-    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel<f16_t>),
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel<f16_t, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRingW));
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel<bf16_t, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRingW));
+    DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel<f16_t, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRingW));
     attr_done = true;
   }
-  if (dtype == kBF16)
-    hipLaunchKernelGGL(wgrad8_kernel<bf16_t>, dim3((unsigned)blocks), dim3(512), kRingW, stream, p);
-  else
-    hipLaunchKernelGGL(wgrad8_kernel<f16_t>, dim3((unsigned)blocks), dim3(512), kRingW, stream, p);
+  const dim3 grid((unsigned)blocks), block(512);
+  if (dtype == kBF16) {
+    if (gather) hipLaunchKernelGGL((wgrad8_kernel<bf16_t, true>), grid, block, kRingW, stream, p);
+    else hipLaunchKernelGGL((wgrad8_kernel<bf16_t, false>), grid, block, kRingW, stream, p);
+  } else {
+    if (gather) hipLaunchKernelGGL((wgrad8_kernel<f16_t, true>), grid, block, kRingW, stream, p);
+    else hipLaunchKernelGGL((wgrad8_kernel<f16_t, false>), grid, block, kRingW, stream, p);
+  }
   DPA_CHECK_HIP(hipGetLastError());
 }
 

@@ -1167,10 +1167,13 @@ def conv_wgrad(dy, x, weight, stride, padding, axf=None):
     if S == 3 and (sh, sw) == (1, 1) and pw == 1 and (OH, OW) == (IH, IW) and axf is None and x.is_contiguous():
         # filter-row kernel: one staged activation row tile per filter ROW instead of per tap (csrc/kernels/wgrad_row3.hip)
         splits, rps = C().wgrad_row3_splits(NB, IH, IW, K, Cx, R, _dt(dy))
-    dense8 = 0
-    if R * S == 1 and (sh, sw) == (1, 1) and ph == 0 and pw == 0 and axf is None and x.is_contiguous() \
-            and dy.is_contiguous():
-        dense8, pps8 = C().wgrad8_splits(M, K, 0, Cx, _dt(dy))
+    dense8 = gather8 = 0
+    if axf is None and x.is_contiguous() and dy.is_contiguous() and splits == 0:
+        # wide layers: the 256 x 256 LDS-DMA pipeline (csrc/kernels/wgrad8.hip), dense or with gathered taps
+        if R * S == 1 and (sh, sw) == (1, 1) and ph == 0 and pw == 0:
+            dense8, pps8 = C().wgrad8_splits(M, K, 0, Cx, _dt(dy))
+        else:
+            gather8, pps8 = C().wgrad8_splits(M, K, 0, Cx, _dt(dy), R * S, True)
     if splits > 0:
         slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
         C().wgrad_row3(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), NB, IH, IW, K, Cx, R, ph, K, Cx, splits, rps,
@@ -1179,6 +1182,12 @@ def conv_wgrad(dy, x, weight, stride, padding, axf=None):
         splits = dense8
         slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
         C().wgrad8(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), M, K, Cx, K, Cx, splits, pps8, _dt(dy), st)
+    elif gather8 > 0:
+        splits = gather8
+        slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)
+        taps = _tap_table(dy.device, _fprop_taps(R, S, ph, pw))
+        C().wgrad(dy.data_ptr(), x.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, K, Cx, R * S, K, Cx, IH, IW,
+                  sh, sw, OH, OW, splits, pps8, 0, _dt(dy), st, use8=1)
     else:
         splits, pps = C().wgrad_choose_splits(M, K, Ktot, _dt(dy))
         slab = torch.empty((splits, K, Ktot), dtype=torch.float32, device=dy.device)

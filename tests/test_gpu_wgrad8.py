@@ -61,3 +61,42 @@ def test_convolution_weight_gradient_takes_the_dma_pipeline_on_deep_layers():
     assert C.wgrad8_splits(1024 * 3136, 64, 0, 256, hip_ops._dt(dy))[0] == 0
     assert C.wgrad8_splits(2000, 1024, 0, 1024, hip_ops._dt(dy))[0] == 0
     assert C.wgrad8_splits(1 << 20, 512, 0, 512, 0)[0] == 0                    # fp32
+
+
+# batch, IH, IW, Cin, Cout, R, S, stride, pad
+CONV_CASES = [
+    (8, 14, 14, 256, 256, 3, 3, 1, 1), (3, 28, 28, 256, 512, 3, 3, 2, 1), (20, 7, 7, 512, 512, 3, 3, 1, 1),
+    (5, 28, 28, 512, 1024, 1, 1, 2, 0), (2, 12, 20, 128, 264, 3, 3, 1, 1), (3, 9, 9, 128, 256, 5, 5, 1, 2),
+    (2, 30, 30, 384, 256, 3, 3, 1, 0), (7, 15, 15, 128, 320, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_gathered_taps_on_the_dma_pipeline(case, dtype):
+    import torch.nn.functional as TF
+    NB, IH, IW, Cin, Cout, R, S, stride, pad = case
+    C = hip_ops.C()
+    torch.manual_seed(4)
+    OH, OW = (IH + 2 * pad - R) // stride + 1, (IW + 2 * pad - S) // stride + 1
+    x = torch.randn(NB, IH, IW, Cin, device=DEV).to(dtype)
+    dy = torch.randn(NB, OH, OW, Cout, device=DEV).to(dtype)
+    w = torch.zeros(Cout, Cin, R, S, device=DEV).contiguous(memory_format=torch.channels_last)
+    try:
+        C.wgrad8_set_mode(1)
+        C.wgrad_row3_set_mode(0)
+        assert C.wgrad8_splits(NB * OH * OW, Cout, 0, Cin, hip_ops._dt(dy), R * S, True)[0] > 0
+        got = hip_ops.conv_wgrad(dy, x, w, (stride, stride), (pad, pad))
+        again = hip_ops.conv_wgrad(dy, x, w, (stride, stride), (pad, pad))
+        C.wgrad8_set_mode(0)
+        old = hip_ops.conv_wgrad(dy, x, w, (stride, stride), (pad, pad))
+    finally:
+        C.wgrad8_set_mode(-1)
+        C.wgrad_row3_set_mode(-1)
+    wr = torch.zeros(Cout, Cin, R, S, device=DEV, requires_grad=True)
+    TF.conv2d(x.float().permute(0, 3, 1, 2), wr, None, stride, pad).backward(dy.float().permute(0, 3, 1, 2))
+    assert_close(got, wr.grad, torch.float32, scale=30, what="wgrad8 gather vs fp32 reference")
+    assert_close(got, old, torch.float32, scale=30, what="wgrad8 gather vs wgrad.hip")
+    assert torch.equal(got, again)
+    # channel counts that are not whole 128-column half-tiles stay on wgrad.hip
+    assert C.wgrad8_splits(1 << 16, 256, 0, 192, hip_ops._dt(dy), 9, True)[0] == 0
