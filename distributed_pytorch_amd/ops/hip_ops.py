@@ -394,7 +394,9 @@ def _wgrad_raw(dy2d_src, x_src, M, N, Cc, IH, IW, gram: bool = False, out_dtype=
     rows = N + (Cc if gram else 0)
     st = _stream()
     # deep layers: the 256 x 256 LDS-DMA pipeline (csrc/kernels/wgrad8.hip); 0 splits = not covered
-    splits, pps = C().wgrad8_splits(M, N, Cc if gram else 0, Cc, _dt(dy2d_src))
+    splits = 0
+    if (dy2d_src.data_ptr() | x_src.data_ptr()) % 16 == 0:
+        splits, pps = C().wgrad8_splits(M, N, Cc if gram else 0, Cc, _dt(dy2d_src))
     if splits > 0:
         slab = torch.empty((splits, rows, Cc), dtype=torch.float32, device=dy2d_src.device)
         C().wgrad8(dy2d_src.data_ptr(), x_src.data_ptr(), slab.data_ptr(), M, N, Cc, ldy, ldx, splits, pps,
@@ -1168,7 +1170,8 @@ def conv_wgrad(dy, x, weight, stride, padding, axf=None):
         # filter-row kernel: one staged activation row tile per filter ROW instead of per tap (csrc/kernels/wgrad_row3.hip)
         splits, rps = C().wgrad_row3_splits(NB, IH, IW, K, Cx, R, _dt(dy))
     dense8 = gather8 = 0
-    if axf is None and x.is_contiguous() and dy.is_contiguous() and splits == 0:
+    if axf is None and x.is_contiguous() and dy.is_contiguous() and splits == 0 \
+            and (x.data_ptr() | dy.data_ptr()) % 16 == 0:
         # wide layers: the 256 x 256 LDS-DMA pipeline (csrc/kernels/wgrad8.hip), dense or with gathered taps
         if R * S == 1 and (sh, sw) == (1, 1) and ph == 0 and pw == 0:
             dense8, pps8 = C().wgrad8_splits(M, K, 0, Cx, _dt(dy))
@@ -2843,10 +2846,18 @@ class _LinearFn(torch.autograd.Function):
             _plain_gemm(dyp, wt, dx, None, M, in_f, outp, outp, outp, in_f, False, cdt, cdt)
             dx = dx.reshape(*lead, in_f)
         if ctx.needs_input_grad[1]:
-            splits, pps = C().wgrad_choose_splits(M, outp, in_f, _dt(cdt))
-            slab = torch.empty((splits, outp, in_f), dtype=torch.float32, device=dy.device)
-            C().wgrad(dyp.data_ptr(), x2.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, outp, in_f, 1,
-                      outp, in_f, 1, 1, 1, 1, 1, 1, splits, pps, 1, _dt(cdt), st)
+            splits = 0
+            if x2.is_contiguous() and dyp.is_contiguous() and (x2.data_ptr() | dyp.data_ptr()) % 16 == 0:
+                splits, pps = C().wgrad8_splits(M, outp, 0, in_f, _dt(cdt))      # wide layers: csrc/kernels/wgrad8.hip
+            if splits > 0:
+                slab = torch.empty((splits, outp, in_f), dtype=torch.float32, device=dy.device)
+                C().wgrad8(dyp.data_ptr(), x2.data_ptr(), slab.data_ptr(), M, outp, in_f, outp, in_f, splits, pps,
+                           _dt(cdt), st)
+            else:
+                splits, pps = C().wgrad_choose_splits(M, outp, in_f, _dt(cdt))
+                slab = torch.empty((splits, outp, in_f), dtype=torch.float32, device=dy.device)
+                C().wgrad(dyp.data_ptr(), x2.data_ptr(), slab.data_ptr(), taps.data_ptr(), M, outp, in_f, 1,
+                          outp, in_f, 1, 1, 1, 1, 1, 1, splits, pps, 1, _dt(cdt), st)
             sink = grad_sink.sink_of(weight)
             if sink is not None and sink.view.is_contiguous() and outp == out_f:
                 # the slab fold writes the gradient straight into the parameter's bucket view
