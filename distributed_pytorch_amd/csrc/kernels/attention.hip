@@ -68,15 +68,34 @@ template <typename T> __device__ __forceinline__ uint4 pack8(const float (&v)[8]
 }
 
 // LDS tile [rows][DP] of T with row stride LD bytes; rows beyond `nrows_valid` and columns beyond D are zero.
+// Eight chunks per thread are requested before the first is stored (one memory latency per trip instead of one per
+// chunk: the per-chunk load -> store loop made the staging the longest phase of a 197-token workgroup), and the
+// (row, chunk) of a thread advances incrementally (no division per chunk).
 template <typename T>
 __device__ __forceinline__ void stage_rows(unsigned char* dst, int LD, const T* __restrict__ src, long src_ld, int row0,
                                            int nrows, int nrows_valid, int D, int DP, int tid, int nthreads) {
+  constexpr int U = 8;
   const int cpr = DP / 8;            // 16-byte chunks per staged row
-  for (int i = tid; i < nrows * cpr; i += nthreads) {
-    const int r = i / cpr, c = i - r * cpr;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row0 + r < nrows_valid && c * 8 < D) v = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * src_ld + c * 8);
-    *reinterpret_cast<uint4*>(dst + r * LD + c * 16) = v;
+  const int total = nrows * cpr;
+  const int dr = nthreads / cpr, dc = nthreads - dr * cpr;
+  int r = tid / cpr, c = tid - r * cpr;
+  for (int i0 = tid; i0 < total; i0 += U * nthreads) {
+    uint4 v[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = make_uint4(0u, 0u, 0u, 0u);
+      off[u] = -1;
+      if (i0 + u * nthreads < total) {
+        off[u] = r * LD + c * 16;
+        if (row0 + r < nrows_valid && c * 8 < D) v[u] = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * src_ld + c * 8);
+      }
+      r += dr; c += dc;
+      if (c >= cpr) { c -= cpr; ++r; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) *reinterpret_cast<uint4*>(dst + off[u]) = v[u];
   }
 }
 
