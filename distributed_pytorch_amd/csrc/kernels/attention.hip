@@ -128,24 +128,39 @@ struct AttnArgs {
   int B, H, S, D, nbias, nsplit;
 };
 
-constexpr int kAttnMaxDB = 4;      // D <= 128.  The kernels are instantiated for MDB = 1, 2, 4 blocks of 32 head
-                                   // channels (D <= 32 / 64 / 128): accumulators and operand fragments are sized by MDB, and
-                                   // sizing them for 128 cost D = 64 heads half their occupancy (419 registers, 1 wave per SIMD)
+constexpr int kAttnMaxDB = 4;      // D <= 128.  The kernels are instantiated for NDB = 1 .. 4 blocks of 32 head channels
+                                   // (D <= 32 / 64 / 96 / 128): accumulators and operand fragments are sized by NDB (sizing
+                                   // them for 128 cost D = 64 heads half their occupancy: 419 registers, 1 wave per SIMD)
 
 // ------------------------------------------------------------------------------------------------ forward / dQ
 // BWD = false: O and log-sum-exp.  BWD = true: dQ (same loop + the dP product).  Workgroup = NW waves = 32 * NW queries of
 // one (b, h); K and V (all S tokens) are staged in LDS once per workgroup (NW = 4 for S > 64: half the staging traffic
 // and twice the waves per LDS byte; NW = 2 for single-window problems, where 4 waves would idle).
-template <typename T, bool BWD, int NW, int MDB>
+//
+// The loop is VALU bound (rocprofv3 --pmc, profiles/r3/pmc_attn.md: 7 % MFMA busy, 70 % VALU), so everything in it is
+// compile-time shaped: NDB = exact number of 32-channel blocks of the head (D padded with zeros; runtime `ks < KS` /
+// `d < NDB` guards made every accumulator a PHI that the compiler shuttled between AGPRs and VGPRs: 208 of 496 VALU
+// instructions per key block), BIAS a template parameter, key-padding masks in the LAST key block only, softmax in the
+// log2 domain (one fma + v_exp_f32 per score), the running-max rescale of the output accumulators only when some
+// lane's maximum moved (a wave-uniform branch: after the first blocks it rarely does).
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+template <typename T> __device__ __forceinline__ uint4 pack8_fast(const float (&v)[8]) { return pack8<T>(v); }
+template <> __device__ __forceinline__ uint4 pack8_fast<bf16_t>(const float (&v)[8]) {
+  f32x2_t a, b, c, d;
+  a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3]; c.x = v[4]; c.y = v[5]; d.x = v[6]; d.y = v[7];
+  return make_uint4(pack_bf16x2(a), pack_bf16x2(b), pack_bf16x2(c), pack_bf16x2(d));
+}
+
+template <typename T, bool BWD, int NW, int NDB, bool BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
+  constexpr int DP = 32 * NDB, KS = 2 * NDB, LD = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int S = a.S, D = a.D, H = a.H;
   const int b = blockIdx.y / H, h = blockIdx.y - b * H;
-  const int DP = (D + 31) / 32 * 32, NDB = DP / 32, KS = (D + 15) / 16;
   const int SP = (S + 31) / 32 * 32;
-  const int LD = DP * 2 + 16;
   unsigned char* sk = smem;
   unsigned char* sv = smem + SP * LD;
   const long row_ld = 3l * H * D;
@@ -156,94 +171,126 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
   const int q = blockIdx.x * (32 * NW) + wave * 32 + l31;       // this lane's query row
   const bool qok = q < S;
   // Q (and dO) fragments straight from global memory: row q, 8 elements at 16*ks + 8*lh
-  uint4 qf[2 * MDB], gf[2 * MDB];
+  uint4 qf[KS], gf[BWD ? KS : 1];
 #pragma unroll
-  for (int ks = 0; ks < 2 * MDB; ++ks) {
-    qf[ks] = gf[ks] = make_uint4(0u, 0u, 0u, 0u);
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = make_uint4(0u, 0u, 0u, 0u);
+    if (BWD) gf[ks] = make_uint4(0u, 0u, 0u, 0u);
     const int c = ks * 16 + lh * 8;
-    if (ks < KS && qok && c < D) {
+    if (qok && c < D) {
       qf[ks] = *reinterpret_cast<const uint4*>(qkv + (long)q * row_ld + c);
       if (BWD) gf[ks] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.dout) +
                                                         ((long)b * S + q) * H * D + (long)h * D + c);
     }
   }
   const float scale = a.scale[h];
-  const float* bias = a.bias ? a.bias + ((long)(b % a.nbias) * H + h) * S * S + (long)(qok ? q : 0) * S : nullptr;
-  float lse_q = 0.f, delta_q = 0.f;
+  const float sl2 = scale * kLog2e;
+  const float* bias = BIAS ? a.bias + ((long)(b % a.nbias) * H + h) * S * S + (long)(qok ? q : 0) * S : nullptr;
+  float lse2 = 0.f, delta_q = 0.f;
   if (BWD && qok) {
-    lse_q = a.lse[((long)b * H + h) * S + q];
+    lse2 = a.lse[((long)b * H + h) * S + q] * kLog2e;
     delta_q = a.delta[((long)b * H + h) * S + q];
   }
+  // per-lane fragment bases: direct reads address row l31 (+ 32 per key block), transposed reads the 4 x 16 sub-block
+  const unsigned char* kdir = sk + l31 * LD + lh * 16;
+  const unsigned char* vdir = sv + l31 * LD + lh * 16;
+  const int g4 = lane >> 4, gi = lane & 15;
+  const int troff = (4 * (g4 >> 1) + (gi >> 2)) * LD + (16 * (g4 & 1) + 4 * (gi & 3)) * 2;
+  const unsigned char* ttr = (BWD ? sk : sv) + troff;
   __syncthreads();
 
-  f32x16_t acc[MDB];
+  f32x16_t acc[NDB];
 #pragma unroll
-  for (int d = 0; d < MDB; ++d)
+  for (int d = 0; d < NDB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const int nkb = SP / 32;
+  const bool ragged = (S & 31) != 0;
 
-  for (int kb = 0; kb < SP / 32; ++kb) {
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int boff = kb * 32 * LD;
     // S^T block: keys <-> registers, queries <-> l31
     f32x16_t sc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2 * MDB; ++ks)
-      if (ks < KS) AMma<T>::run(sc, frag_direct(sk, LD, kb * 32 + l31, ks, lh), qf[ks]);
+    for (int ks = 0; ks < KS; ++ks)
+      AMma<T>::run(sc, *reinterpret_cast<const uint4*>(kdir + boff + ks * 32), qf[ks]);
     float p[16];
-    float mblk = -INFINITY;
+    if (BIAS) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kb * 32 + reg_row(r, lh);
-      float s = sc[r] * scale;
-      if (bias != nullptr && key < S) s += bias[key];
-      if (key >= S) s = -INFINITY;
-      p[r] = s;
-      mblk = fmaxf(mblk, s);
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + reg_row(r, lh);
+        p[r] = fmaf(sc[r], sl2, (key < S ? bias[key] : 0.f) * kLog2e);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] = sc[r] * sl2;
     }
+    const bool tail = ragged && kb == nkb - 1;        // workgroup-uniform
     if (!BWD) {
+      if (tail) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + reg_row(r, lh) >= S) p[r] = -INFINITY;
+      }
+      float mblk = p[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mblk = fmaxf(mblk, p[r]);
       mblk = fmaxf(mblk, __shfl_xor(mblk, 32, 64));
-      const float m_new = fmaxf(m_run, mblk);
-      const float alpha = m_run == -INFINITY ? 0.f : __expf(m_run - m_new);
+      // a finite floor: a fully masked block (never the first) then gives exp2(-inf) = 0 without a select
+      const float m_new = fmaxf(fmaxf(m_run, mblk), -3.0e38f);
+      if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+        m_run = m_new;
+      }
       float lsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = m_new == -INFINITY ? 0.f : __expf(p[r] - m_new);
+        p[r] = __builtin_amdgcn_exp2f(p[r] - m_run);
         lsum += p[r];
       }
-      l_run = l_run * alpha + lsum;
-      m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < MDB; ++d)
-        if (d < NDB)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+      l_run += lsum;
     } else {
       // P from the saved log-sum-exp, dP^T = V dO^T, dS^T = P (dP - delta)
       f32x16_t dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 2 * MDB; ++ks)
-        if (ks < KS) AMma<T>::run(dp, frag_direct(sv, LD, kb * 32 + l31, ks, lh), gf[ks]);
+      for (int ks = 0; ks < KS; ++ks)
+        AMma<T>::run(dp, *reinterpret_cast<const uint4*>(vdir + boff + ks * 32), gf[ks]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pr = (qok && p[r] != -INFINITY) ? __expf(p[r] - lse_q) : 0.f;
+        const float pr = __builtin_amdgcn_exp2f(p[r] - lse2);
         p[r] = pr * (dp[r] - delta_q) * scale;           // gradient of the raw Q.K product
+      }
+      // lanes without a query have zero operands, lse2 = delta = 0: p = 0 already.  Padding keys (zero K rows) would
+      // contribute exp2(-lse2) * dp: masked here, in the last block only
+      if (tail) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + reg_row(r, lh) >= S) p[r] = 0.f;
       }
     }
     // acc[d][query] += sum_key p[key] * (V | K)[key][d]: the probabilities are the B operand as they sit
-    const unsigned char* tile = BWD ? sk : sv;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       float half[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) half[j] = p[8 * s2 + j];
-      const uint4 pf = pack8<T>(half);
+      const uint4 pf = pack8_fast<T>(half);
 #pragma unroll
-      for (int d = 0; d < MDB; ++d)
-        if (d < NDB) AMma<T>::run(acc[d], frag_tr(tile, LD, kb * 32 + 16 * s2, d * 32, lane), pf);
+      for (int d = 0; d < NDB; ++d) {
+        const unsigned char* base = ttr + boff + 16 * s2 * LD + d * 64;
+        const uint2 lo = attn_tr_read(base), hi = attn_tr_read(base + 8 * LD);
+        AMma<T>::run(acc[d], make_uint4(lo.x, lo.y, hi.x, hi.y), pf);
+      }
     }
   }
 
@@ -253,56 +300,55 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
     if (qok) {
       T* o = reinterpret_cast<T*>(a.out) + ((long)b * S + q) * H * D + (long)h * D;
 #pragma unroll
-      for (int d = 0; d < MDB; ++d)
-        if (d < NDB)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int c = d * 32 + 8 * g + 4 * lh;
-            if (c < D) {       // D is a multiple of 8: 4 consecutive channels are all in or all out
-              T v4[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v4[j] = from_float<T>(acc[d][4 * g + j] * inv);
-              uint2 w;
-              __builtin_memcpy(&w, v4, 8);
-              *reinterpret_cast<uint2*>(o + c) = w;
-            }
-          }
-      if (lh == 0) a.lse[((long)b * H + h) * S + q] = m_run + __logf(l_tot);
-    }
-  } else if (qok) {
-    T* o = reinterpret_cast<T*>(a.dqkv) + ((long)b * S + q) * row_ld + (long)h * D;
-#pragma unroll
-    for (int d = 0; d < MDB; ++d)
-      if (d < NDB)
+      for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = d * 32 + 8 * g + 4 * lh;
-          if (c < D) {
+          if (c < D) {       // D is a multiple of 8: 4 consecutive channels are all in or all out
             T v4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v4[j] = from_float<T>(acc[d][4 * g + j]);
+            for (int j = 0; j < 4; ++j) v4[j] = from_float<T>(acc[d][4 * g + j] * inv);
             uint2 w;
             __builtin_memcpy(&w, v4, 8);
             *reinterpret_cast<uint2*>(o + c) = w;
           }
         }
+      if (lh == 0) a.lse[((long)b * H + h) * S + q] = m_run * kLn2 + __logf(l_tot);
+    }
+  } else if (qok) {
+    T* o = reinterpret_cast<T*>(a.dqkv) + ((long)b * S + q) * row_ld + (long)h * D;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = d * 32 + 8 * g + 4 * lh;
+        if (c < D) {
+          T v4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v4[j] = from_float<T>(acc[d][4 * g + j]);
+          uint2 w;
+          __builtin_memcpy(&w, v4, 8);
+          *reinterpret_cast<uint2*>(o + c) = w;
+        }
+      }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV (, dbias)
-// Workgroup = 2 waves = 64 keys of head h; it walks batch entries b = split, split + nsplit, ...  Q and dO of the
+// Workgroup = NW waves = 32 * NW keys of head h; it walks batch entries b = split, split + nsplit, ...  Q and dO of the
 // current (b, h) are staged in LDS (all S tokens), the wave's own K / V rows are read as fragments from global memory.
 // DBIAS (S <= 64: one workgroup covers every key): dS accumulates in registers over the strip of batch entries.
-template <typename T, bool DBIAS, int NW, int MDB>
-__global__ __launch_bounds__(64 * NW, MDB <= 2 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
+// No masks: padded query rows are zero rows of Q and dO with lse = delta = 0 (P = 1 meets dO = 0, dS = 0), lanes without
+// a key compute values that are never stored.  lse is staged pre-multiplied by log2(e).
+template <typename T, bool DBIAS, int NW, int NDB, bool BIAS>
+__global__ __launch_bounds__(64 * NW, NDB <= 2 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
+  constexpr int DP = 32 * NDB, KS = 2 * NDB, LD = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int S = a.S, D = a.D, H = a.H;
   const int split = blockIdx.y / H, h = blockIdx.y - split * H;
-  const int DP = (D + 31) / 32 * 32, NDB = DP / 32, KS = (D + 15) / 16;
   const int SP = (S + 31) / 32 * 32;
-  const int LD = DP * 2 + 16;
   unsigned char* sq = smem;
   unsigned char* sg = smem + SP * LD;
   float* s_lse = reinterpret_cast<float*>(smem + 2 * SP * LD);
@@ -311,6 +357,11 @@ __global__ __launch_bounds__(64 * NW, MDB <= 2 ? 2 : 1) void attn_kv_kernel(cons
   const int key = blockIdx.x * (32 * NW) + wave * 32 + l31;     // this lane's key row
   const bool kok = key < S;
   const float scale = a.scale[h];
+  const float sl2 = scale * kLog2e;
+  const unsigned char* qdir = sq + l31 * LD + lh * 16;
+  const unsigned char* gdir = sg + l31 * LD + lh * 16;
+  const int g4 = lane >> 4, gi = lane & 15;
+  const int troff = (4 * (g4 >> 1) + (gi >> 2)) * LD + (16 * (g4 & 1) + 4 * (gi & 3)) * 2;
 
   f32x16_t dsacc[DBIAS ? 2 : 1];
 #pragma unroll
@@ -325,50 +376,60 @@ __global__ __launch_bounds__(64 * NW, MDB <= 2 ? 2 : 1) void attn_kv_kernel(cons
     stage_rows<T>(sq, LD, qkv, row_ld, 0, SP, S, D, DP, tid, 64 * NW);
     stage_rows<T>(sg, LD, dout, (long)H * D, 0, SP, S, D, DP, tid, 64 * NW);
     for (int i = tid; i < SP; i += 64 * NW) {
-      s_lse[i] = i < S ? a.lse[((long)b * H + h) * S + i] : 0.f;
+      s_lse[i] = i < S ? a.lse[((long)b * H + h) * S + i] * kLog2e : 0.f;
       s_delta[i] = i < S ? a.delta[((long)b * H + h) * S + i] : 0.f;
     }
-    uint4 kf[2 * MDB], vf[2 * MDB];
+    uint4 kf[KS], vf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2 * MDB; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       kf[ks] = vf[ks] = make_uint4(0u, 0u, 0u, 0u);
       const int c = ks * 16 + lh * 8;
-      if (ks < KS && kok && c < D) {
+      if (kok && c < D) {
         kf[ks] = *reinterpret_cast<const uint4*>(qkv + (long)key * row_ld + (long)H * D + c);
         vf[ks] = *reinterpret_cast<const uint4*>(qkv + (long)key * row_ld + 2l * H * D + c);
       }
     }
-    const float* bias = a.bias ? a.bias + ((long)(b % a.nbias) * H + h) * S * S : nullptr;
+    const float* bias = BIAS ? a.bias + ((long)(b % a.nbias) * H + h) * S * S : nullptr;
     __syncthreads();
 
-    f32x16_t dk[MDB], dv[MDB];
+    f32x16_t dk[NDB], dv[NDB];
 #pragma unroll
-    for (int d = 0; d < MDB; ++d)
+    for (int d = 0; d < NDB; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
 
     for (int qb = 0; qb < SP / 32; ++qb) {
+      const int boff = qb * 32 * LD;
       // S block: queries <-> registers, keys <-> l31
       f32x16_t sc, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 2 * MDB; ++ks)
-        if (ks < KS) {
-          AMma<T>::run(sc, frag_direct(sq, LD, qb * 32 + l31, ks, lh), kf[ks]);
-          AMma<T>::run(dp, frag_direct(sg, LD, qb * 32 + l31, ks, lh), vf[ks]);
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        AMma<T>::run(sc, *reinterpret_cast<const uint4*>(qdir + boff + ks * 32), kf[ks]);
+        AMma<T>::run(dp, *reinterpret_cast<const uint4*>(gdir + boff + ks * 32), vf[ks]);
+      }
       float p[16], ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qrow = qb * 32 + reg_row(r, lh);
-        float s = sc[r] * scale;
-        if (bias != nullptr && qrow < S && kok) s += bias[(long)qrow * S + key];
-        const float pr = (qrow < S && kok) ? __expf(s - s_lse[qrow]) : 0.f;
-        p[r] = pr;
-        ds[r] = pr * (dp[r] - s_delta[qrow]);
-        if (DBIAS) dsacc[qb & 1][r] += ds[r];
-        ds[r] *= scale;
+      for (int g = 0; g < 4; ++g) {
+        // registers 4g .. 4g+3 are query rows qb*32 + 8g + 4lh + 0..3: one 16-byte read of each per-row table
+        const float4 l4 = *reinterpret_cast<const float4*>(s_lse + qb * 32 + 8 * g + 4 * lh);
+        const float4 d4 = *reinterpret_cast<const float4*>(s_delta + qb * 32 + 8 * g + 4 * lh);
+        const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float s = fmaf(sc[r], sl2, -lr[j]);
+          if (BIAS) {
+            const int qrow = qb * 32 + 8 * g + 4 * lh + j;
+            s = fmaf((qrow < S && kok) ? bias[(long)qrow * S + key] : 0.f, kLog2e, s);
+          }
+          const float pr = __builtin_amdgcn_exp2f(s);
+          p[r] = pr;
+          ds[r] = pr * (dp[r] - dr[j]);
+          if (DBIAS) dsacc[qb & 1][r] += ds[r];
+          ds[r] *= scale;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -378,37 +439,39 @@ __global__ __launch_bounds__(64 * NW, MDB <= 2 ? 2 : 1) void attn_kv_kernel(cons
           hp[j] = p[8 * s2 + j];
           hd[j] = ds[8 * s2 + j];
         }
-        const uint4 pf = pack8<T>(hp), df = pack8<T>(hd);
+        const uint4 pf = pack8_fast<T>(hp), df = pack8_fast<T>(hd);
 #pragma unroll
-        for (int d = 0; d < MDB; ++d)
-          if (d < NDB) {
-            AMma<T>::run(dv[d], frag_tr(sg, LD, qb * 32 + 16 * s2, d * 32, lane), pf);   // dV += P^T dO
-            AMma<T>::run(dk[d], frag_tr(sq, LD, qb * 32 + 16 * s2, d * 32, lane), df);   // dK += dS^T Q
-          }
+        for (int d = 0; d < NDB; ++d) {
+          const unsigned char* bg = sg + troff + boff + 16 * s2 * LD + d * 64;
+          const unsigned char* bq = sq + troff + boff + 16 * s2 * LD + d * 64;
+          const uint2 glo = attn_tr_read(bg), ghi = attn_tr_read(bg + 8 * LD);
+          const uint2 qlo = attn_tr_read(bq), qhi = attn_tr_read(bq + 8 * LD);
+          AMma<T>::run(dv[d], make_uint4(glo.x, glo.y, ghi.x, ghi.y), pf);   // dV += P^T dO
+          AMma<T>::run(dk[d], make_uint4(qlo.x, qlo.y, qhi.x, qhi.y), df);   // dK += dS^T Q
+        }
       }
     }
     if (kok) {
       T* o = reinterpret_cast<T*>(a.dqkv) + ((long)b * S + key) * row_ld + (long)h * D;
 #pragma unroll
-      for (int d = 0; d < MDB; ++d)
-        if (d < NDB)
+      for (int d = 0; d < NDB; ++d)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int c = d * 32 + 8 * g + 4 * lh;
-            if (c < D) {
-              T k4[4], v4[4];
+        for (int g = 0; g < 4; ++g) {
+          const int c = d * 32 + 8 * g + 4 * lh;
+          if (c < D) {
+            T k4[4], v4[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                k4[j] = from_float<T>(dk[d][4 * g + j]);
-                v4[j] = from_float<T>(dv[d][4 * g + j]);
-              }
-              uint2 w;
-              __builtin_memcpy(&w, k4, 8);
-              *reinterpret_cast<uint2*>(o + (long)H * D + c) = w;
-              __builtin_memcpy(&w, v4, 8);
-              *reinterpret_cast<uint2*>(o + 2l * H * D + c) = w;
+            for (int j = 0; j < 4; ++j) {
+              k4[j] = from_float<T>(dk[d][4 * g + j]);
+              v4[j] = from_float<T>(dv[d][4 * g + j]);
             }
+            uint2 w;
+            __builtin_memcpy(&w, k4, 8);
+            *reinterpret_cast<uint2*>(o + (long)H * D + c) = w;
+            __builtin_memcpy(&w, v4, 8);
+            *reinterpret_cast<uint2*>(o + 2l * H * D + c) = w;
           }
+        }
     }
   }
   if (DBIAS && kok) {
@@ -644,16 +707,20 @@ void attn_fwd_launch(const void* qkv, void* out, float* lse, const float* bias, 
   const int lds = lds_bytes(S, D, false);
   const int nw = S > 64 ? 4 : 2;
   dim3 grid(ceil_div(S, 32 * nw), B * H);
-#define DPA_ATTN_FWD2(T, NW, MDB)                                                            \
-  set_lds(attn_q_kernel<T, false, NW, MDB>, lds);                                            \
-  hipLaunchKernelGGL((attn_q_kernel<T, false, NW, MDB>), grid, dim3(64 * NW), lds, s, a);
-#define DPA_ATTN_FWD(T, NW)                                                                  \
-  if (D <= 32) { DPA_ATTN_FWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_FWD2(T, NW, 2) } else { DPA_ATTN_FWD2(T, NW, 4) }
+#define DPA_ATTN_FWD3(T, NW, NDB, BIAS)                                                            \
+  set_lds(attn_q_kernel<T, false, NW, NDB, BIAS>, lds);                                            \
+  hipLaunchKernelGGL((attn_q_kernel<T, false, NW, NDB, BIAS>), grid, dim3(64 * NW), lds, s, a);
+#define DPA_ATTN_FWD2(T, NW, NDB)                                                                  \
+  if (bias != nullptr) { DPA_ATTN_FWD3(T, NW, NDB, true) } else { DPA_ATTN_FWD3(T, NW, NDB, false) }
+#define DPA_ATTN_FWD(T, NW)                                                                        \
+  if (D <= 32) { DPA_ATTN_FWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_FWD2(T, NW, 2) }           \
+  else if (D <= 96) { DPA_ATTN_FWD2(T, NW, 3) } else { DPA_ATTN_FWD2(T, NW, 4) }
   if (dtype == kBF16) {
     if (nw == 4) { DPA_ATTN_FWD(bf16_t, 4) } else { DPA_ATTN_FWD(bf16_t, 2) }
   } else {
     if (nw == 4) { DPA_ATTN_FWD(f16_t, 4) } else { DPA_ATTN_FWD(f16_t, 2) }
   }
+#undef DPA_ATTN_FWD3
 #undef DPA_ATTN_FWD2
 #undef DPA_ATTN_FWD
   DPA_CHECK_HIP(hipGetLastError());
@@ -681,25 +748,29 @@ void attn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
   const int lds_q = lds_bytes(S, D, false), lds_kv = lds_bytes(S, D, true);
   const int nw = S > 64 ? 4 : 2;
   dim3 gq(ceil_div(S, 32 * nw), B * H), gkv(ceil_div(S, 32 * nw), a.nsplit * H);
-#define DPA_ATTN_BWD2(T, NW, MDB)                                                                                    \
-  set_lds(attn_q_kernel<T, true, NW, MDB>, lds_q);                                                                   \
-  hipLaunchKernelGGL((attn_q_kernel<T, true, NW, MDB>), gq, dim3(64 * NW), lds_q, s, a);                             \
+#define DPA_ATTN_BWD3(T, NW, NDB, BIAS)                                                                              \
+  set_lds(attn_q_kernel<T, true, NW, NDB, BIAS>, lds_q);                                                             \
+  hipLaunchKernelGGL((attn_q_kernel<T, true, NW, NDB, BIAS>), gq, dim3(64 * NW), lds_q, s, a);                       \
   if (dbias != nullptr) {                                                                                            \
-    set_lds(attn_kv_kernel<T, true, 2, MDB>, lds_kv);                                                                \
-    hipLaunchKernelGGL((attn_kv_kernel<T, true, 2, MDB>), gkv, dim3(128), lds_kv, s, a);                             \
+    set_lds(attn_kv_kernel<T, true, 2, NDB, true>, lds_kv);                                                          \
+    hipLaunchKernelGGL((attn_kv_kernel<T, true, 2, NDB, true>), gkv, dim3(128), lds_kv, s, a);                       \
   } else {                                                                                                           \
-    set_lds(attn_kv_kernel<T, false, NW, MDB>, lds_kv);                                                              \
-    hipLaunchKernelGGL((attn_kv_kernel<T, false, NW, MDB>), gkv, dim3(64 * NW), lds_kv, s, a);                       \
+    set_lds(attn_kv_kernel<T, false, NW, NDB, BIAS>, lds_kv);                                                        \
+    hipLaunchKernelGGL((attn_kv_kernel<T, false, NW, NDB, BIAS>), gkv, dim3(64 * NW), lds_kv, s, a);                 \
   }
+#define DPA_ATTN_BWD2(T, NW, NDB)                                                                                    \
+  if (bias != nullptr) { DPA_ATTN_BWD3(T, NW, NDB, true) } else { DPA_ATTN_BWD3(T, NW, NDB, false) }
 #define DPA_ATTN_BWD(T, NW)                                                                                          \
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(dgrid), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, rows, H, \
                      S, D);                                                                                          \
-  if (D <= 32) { DPA_ATTN_BWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_BWD2(T, NW, 2) } else { DPA_ATTN_BWD2(T, NW, 4) }
+  if (D <= 32) { DPA_ATTN_BWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_BWD2(T, NW, 2) }                             \
+  else if (D <= 96) { DPA_ATTN_BWD2(T, NW, 3) } else { DPA_ATTN_BWD2(T, NW, 4) }
   if (dtype == kBF16) {
     if (nw == 4) { DPA_ATTN_BWD(bf16_t, 4) } else { DPA_ATTN_BWD(bf16_t, 2) }
   } else {
     if (nw == 4) { DPA_ATTN_BWD(f16_t, 4) } else { DPA_ATTN_BWD(f16_t, 2) }
   }
+#undef DPA_ATTN_BWD3
 #undef DPA_ATTN_BWD2
 #undef DPA_ATTN_BWD
   DPA_CHECK_HIP(hipGetLastError());
