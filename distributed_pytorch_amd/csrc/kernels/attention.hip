@@ -134,8 +134,9 @@ constexpr int kAttnMaxDB = 4;      // D <= 128.  The kernels are instantiated fo
 
 // ------------------------------------------------------------------------------------------------ forward / dQ
 // BWD = false: O and log-sum-exp.  BWD = true: dQ (same loop + the dP product).  Workgroup = NW waves = 32 * NW queries of
-// one (b, h); K and V (all S tokens) are staged in LDS once per workgroup (NW = 4 for S > 64: half the staging traffic
-// and twice the waves per LDS byte; NW = 2 for single-window problems, where 4 waves would idle).
+// one (b, h); K and V (all S tokens) are staged in LDS once per workgroup.  NW (the launch's block size) is the number of
+// 32-query blocks when that is <= 8 -- ONE workgroup per (b, h): S = 197 runs 7 waves and stages K / V once, where 2
+// workgroups of 4 waves staged them twice and idled a wave -- otherwise the blocks are split evenly over workgroups.
 //
 // The loop is VALU bound (rocprofv3 --pmc, profiles/r3/pmc_attn.md: 7 % MFMA busy, 70 % VALU), so everything in it is
 // compile-time shaped: NDB = exact number of 32-channel blocks of the head (D padded with zeros; runtime `ks < KS` /
@@ -152,11 +153,12 @@ template <> __device__ __forceinline__ uint4 pack8_fast<bf16_t>(const float (&v)
   return make_uint4(pack_bf16x2(a), pack_bf16x2(b), pack_bf16x2(c), pack_bf16x2(d));
 }
 
-template <typename T, bool BWD, int NW, int NDB, bool BIAS>
-__global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
+template <typename T, bool BWD, int NDB, bool BIAS>
+__global__ __launch_bounds__(512) void attn_q_kernel(const AttnArgs a) {
   constexpr int DP = 32 * NDB, KS = 2 * NDB, LD = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NW = (int)(blockDim.x >> 6);          // 1 .. 8 waves: attn_waves()
   const int l31 = lane & 31, lh = lane >> 5;
   const int S = a.S, D = a.D, H = a.H;
   const int b = blockIdx.y / H, h = blockIdx.y - b * H;
@@ -340,11 +342,12 @@ __global__ __launch_bounds__(64 * NW) void attn_q_kernel(const AttnArgs a) {
 // DBIAS (S <= 64: one workgroup covers every key): dS accumulates in registers over the strip of batch entries.
 // No masks: padded query rows are zero rows of Q and dO with lse = delta = 0 (P = 1 meets dO = 0, dS = 0), lanes without
 // a key compute values that are never stored.  lse is staged pre-multiplied by log2(e).
-template <typename T, bool DBIAS, int NW, int NDB, bool BIAS>
-__global__ __launch_bounds__(64 * NW, NDB <= 2 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
+template <typename T, bool DBIAS, int NDB, bool BIAS>
+__global__ __launch_bounds__(DBIAS ? 128 : (NDB <= 2 ? 512 : 256), DBIAS && NDB <= 2 ? 2 : 1) void attn_kv_kernel(const AttnArgs a) {
   constexpr int DP = 32 * NDB, KS = 2 * NDB, LD = DP * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NW = (int)(blockDim.x >> 6);          // DBIAS: 2 waves (S <= 64); otherwise attn_waves()
   const int l31 = lane & 31, lh = lane >> 5;
   const int S = a.S, D = a.D, H = a.H;
   const int split = blockIdx.y / H, h = blockIdx.y - split * H;
@@ -486,28 +489,40 @@ __global__ __launch_bounds__(64 * NW, NDB <= 2 ? 2 : 1) void attn_kv_kernel(cons
   }
 }
 
-// delta[b][h][s] = sum_d dO * O  (one wave per 64 / (D/8) rows: a row of D elements is D/8 lanes of 16 bytes)
+// delta[b][h][s] = sum_d dO * O.  One lane per 16-byte chunk: the D / 8 lanes of a row read one contiguous row segment
+// (a lane per row made every load instruction touch 64 different 128-byte lines: 80 us for 78 MB), partial dot
+// products meet in LDS and the first lanes of the workgroup add the D / 8 partials of their row.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
                                                          float* __restrict__ delta, long rows_bs, int H, int S, int D) {
-  // one thread per (b, s, h): D <= 128 elements, 16-byte loads
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows_bs * H) return;
-  const long bs = i / H;
-  const int h = (int)(i - bs * H);
-  const T* po = o + bs * H * D + (long)h * D;
-  const T* pg = dout + bs * H * D + (long)h * D;
+  __shared__ float part[256];
+  const int lpr = D >> 3;                        // lanes per row (D is a multiple of 8, <= 128)
+  const int rpw = 256 / lpr;                     // rows per workgroup
+  const int t = threadIdx.x;
+  const int rl = t / lpr, cl = t - rl * lpr;
+  const long row = (long)blockIdx.x * rpw + rl;  // (b, s, h) flattened: [B*S][H] rows of D elements, contiguous
   float acc = 0.f;
-  for (int c = 0; c < D; c += 8) {
+  if (rl < rpw && row < rows_bs * H) {
     Vec16<T> vo, vg;
-    vo.load(po + c);
-    vg.load(pg + c);
+    vo.load(o + row * D + cl * 8);
+    vg.load(dout + row * D + cl * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc += vo.get(j) * vg.get(j);
   }
-  const long b = bs / S;
-  const int s = (int)(bs - b * S);
-  delta[(b * H + h) * S + s] = acc;
+  part[t] = acc;
+  __syncthreads();
+  if (t < rpw) {
+    const long r = (long)blockIdx.x * rpw + t;
+    if (r < rows_bs * H) {
+      float sum = 0.f;
+      for (int j = 0; j < lpr; ++j) sum += part[t * lpr + j];
+      const long bs = r / H;
+      const int h = (int)(r - bs * H);
+      const long b = bs / S;
+      const int sidx = (int)(bs - b * S);
+      delta[(b * H + h) * S + sidx] = sum;
+    }
+  }
 }
 
 // ---- window / grid partition of NHWC token maps (Swin, MaxViT) ------------------------------------------------------
@@ -644,6 +659,12 @@ int lds_bytes(int S, int D, bool with_rows) {
   return 2 * SP * (DP * 2 + 16) + (with_rows ? 2 * SP * 4 : 0);
 }
 
+// waves per workgroup: the 32-token blocks of a sequence in one workgroup when there are at most 8, else split evenly
+int attn_waves(int S, int maxw = 8) {
+  const int nblk = (S + 31) / 32, nwg = (nblk + maxw - 1) / maxw;
+  return (nblk + nwg - 1) / nwg;
+}
+
 template <typename K> void set_lds(K kern, int lds) {
   if (lds > 64 * 1024)
     DPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -705,21 +726,17 @@ void attn_fwd_launch(const void* qkv, void* out, float* lse, const float* bias, 
   a.qkv = qkv; a.out = out; a.lse = lse; a.bias = bias; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale;
   a.B = B; a.H = H; a.S = S; a.D = D;
   const int lds = lds_bytes(S, D, false);
-  const int nw = S > 64 ? 4 : 2;
+  const int nw = attn_waves(S);
   dim3 grid(ceil_div(S, 32 * nw), B * H);
-#define DPA_ATTN_FWD3(T, NW, NDB, BIAS)                                                            \
-  set_lds(attn_q_kernel<T, false, NW, NDB, BIAS>, lds);                                            \
-  hipLaunchKernelGGL((attn_q_kernel<T, false, NW, NDB, BIAS>), grid, dim3(64 * NW), lds, s, a);
-#define DPA_ATTN_FWD2(T, NW, NDB)                                                                  \
-  if (bias != nullptr) { DPA_ATTN_FWD3(T, NW, NDB, true) } else { DPA_ATTN_FWD3(T, NW, NDB, false) }
-#define DPA_ATTN_FWD(T, NW)                                                                        \
-  if (D <= 32) { DPA_ATTN_FWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_FWD2(T, NW, 2) }           \
-  else if (D <= 96) { DPA_ATTN_FWD2(T, NW, 3) } else { DPA_ATTN_FWD2(T, NW, 4) }
-  if (dtype == kBF16) {
-    if (nw == 4) { DPA_ATTN_FWD(bf16_t, 4) } else { DPA_ATTN_FWD(bf16_t, 2) }
-  } else {
-    if (nw == 4) { DPA_ATTN_FWD(f16_t, 4) } else { DPA_ATTN_FWD(f16_t, 2) }
-  }
+#define DPA_ATTN_FWD3(T, NDB, BIAS)                                                            \
+  set_lds(attn_q_kernel<T, false, NDB, BIAS>, lds);                                            \
+  hipLaunchKernelGGL((attn_q_kernel<T, false, NDB, BIAS>), grid, dim3(64 * nw), lds, s, a);
+#define DPA_ATTN_FWD2(T, NDB)                                                                  \
+  if (bias != nullptr) { DPA_ATTN_FWD3(T, NDB, true) } else { DPA_ATTN_FWD3(T, NDB, false) }
+#define DPA_ATTN_FWD(T)                                                                        \
+  if (D <= 32) { DPA_ATTN_FWD2(T, 1) } else if (D <= 64) { DPA_ATTN_FWD2(T, 2) }               \
+  else if (D <= 96) { DPA_ATTN_FWD2(T, 3) } else { DPA_ATTN_FWD2(T, 4) }
+  if (dtype == kBF16) { DPA_ATTN_FWD(bf16_t) } else { DPA_ATTN_FWD(f16_t) }
 #undef DPA_ATTN_FWD3
 #undef DPA_ATTN_FWD2
 #undef DPA_ATTN_FWD
@@ -744,32 +761,29 @@ void attn_bwd_launch(const void* qkv, const void* out, const void* dout, const f
   a.nbias = nbias > 0 ? nbias : 1; a.scale = scale; a.dout = dout; a.delta = delta; a.dqkv = dqkv; a.dbias = dbias;
   a.B = B; a.H = H; a.S = S; a.D = D; a.nsplit = dbias != nullptr ? nsplit : B;
   const long rows = (long)B * S;
-  const int dgrid = ceil_div(rows * H, 256);
+  const int dgrid = (int)ceil_div(rows * H, (long)(256 / (D / 8)));
   const int lds_q = lds_bytes(S, D, false), lds_kv = lds_bytes(S, D, true);
-  const int nw = S > 64 ? 4 : 2;
-  dim3 gq(ceil_div(S, 32 * nw), B * H), gkv(ceil_div(S, 32 * nw), a.nsplit * H);
-#define DPA_ATTN_BWD3(T, NW, NDB, BIAS)                                                                              \
-  set_lds(attn_q_kernel<T, true, NW, NDB, BIAS>, lds_q);                                                             \
-  hipLaunchKernelGGL((attn_q_kernel<T, true, NW, NDB, BIAS>), gq, dim3(64 * NW), lds_q, s, a);                       \
+  // dK / dV with D > 64 needs more than 256 registers: at most 4 waves per workgroup there (one per SIMD)
+  const int nw = attn_waves(S), nwk = attn_waves(S, D <= 64 ? 8 : 4);
+  dim3 gq(ceil_div(S, 32 * nw), B * H), gkv(ceil_div(S, 32 * nwk), a.nsplit * H);
+#define DPA_ATTN_BWD3(T, NDB, BIAS)                                                                                  \
+  set_lds(attn_q_kernel<T, true, NDB, BIAS>, lds_q);                                                                 \
+  hipLaunchKernelGGL((attn_q_kernel<T, true, NDB, BIAS>), gq, dim3(64 * nw), lds_q, s, a);                           \
   if (dbias != nullptr) {                                                                                            \
-    set_lds(attn_kv_kernel<T, true, 2, NDB, true>, lds_kv);                                                          \
-    hipLaunchKernelGGL((attn_kv_kernel<T, true, 2, NDB, true>), gkv, dim3(128), lds_kv, s, a);                       \
+    set_lds(attn_kv_kernel<T, true, NDB, true>, lds_kv);                                                             \
+    hipLaunchKernelGGL((attn_kv_kernel<T, true, NDB, true>), dim3(1, a.nsplit * H), dim3(128), lds_kv, s, a);        \
   } else {                                                                                                           \
-    set_lds(attn_kv_kernel<T, false, NW, NDB, BIAS>, lds_kv);                                                        \
-    hipLaunchKernelGGL((attn_kv_kernel<T, false, NW, NDB, BIAS>), gkv, dim3(64 * NW), lds_kv, s, a);                 \
+    set_lds(attn_kv_kernel<T, false, NDB, BIAS>, lds_kv);                                                            \
+    hipLaunchKernelGGL((attn_kv_kernel<T, false, NDB, BIAS>), gkv, dim3(64 * nwk), lds_kv, s, a);                    \
   }
-#define DPA_ATTN_BWD2(T, NW, NDB)                                                                                    \
-  if (bias != nullptr) { DPA_ATTN_BWD3(T, NW, NDB, true) } else { DPA_ATTN_BWD3(T, NW, NDB, false) }
-#define DPA_ATTN_BWD(T, NW)                                                                                          \
+#define DPA_ATTN_BWD2(T, NDB)                                                                                        \
+  if (bias != nullptr) { DPA_ATTN_BWD3(T, NDB, true) } else { DPA_ATTN_BWD3(T, NDB, false) }
+#define DPA_ATTN_BWD(T)                                                                                              \
   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(dgrid), dim3(256), 0, s, (const T*)out, (const T*)dout, delta, rows, H, \
                      S, D);                                                                                          \
-  if (D <= 32) { DPA_ATTN_BWD2(T, NW, 1) } else if (D <= 64) { DPA_ATTN_BWD2(T, NW, 2) }                             \
-  else if (D <= 96) { DPA_ATTN_BWD2(T, NW, 3) } else { DPA_ATTN_BWD2(T, NW, 4) }
-  if (dtype == kBF16) {
-    if (nw == 4) { DPA_ATTN_BWD(bf16_t, 4) } else { DPA_ATTN_BWD(bf16_t, 2) }
-  } else {
-    if (nw == 4) { DPA_ATTN_BWD(f16_t, 4) } else { DPA_ATTN_BWD(f16_t, 2) }
-  }
+  if (D <= 32) { DPA_ATTN_BWD2(T, 1) } else if (D <= 64) { DPA_ATTN_BWD2(T, 2) }                                     \
+  else if (D <= 96) { DPA_ATTN_BWD2(T, 3) } else { DPA_ATTN_BWD2(T, 4) }
+  if (dtype == kBF16) { DPA_ATTN_BWD(bf16_t) } else { DPA_ATTN_BWD(f16_t) }
 #undef DPA_ATTN_BWD3
 #undef DPA_ATTN_BWD2
 #undef DPA_ATTN_BWD
