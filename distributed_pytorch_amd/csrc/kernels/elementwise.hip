@@ -88,6 +88,47 @@ __global__ __launch_bounds__(256) void to_s2d_kernel(const TI* __restrict__ x, T
   }
 }
 
+// The prefetcher's case (uint8 NHWC source): one thread per s2d pixel, one workgroup per output row (no divisions).  The
+// 12 source bytes of a pixel are two runs of 6 contiguous bytes (rows 2Y and 2Y+1, columns 2X and 2X+1), 2-byte aligned
+// because W is even: three 16-bit loads each instead of twelve byte loads, and both 16-byte chunks leave in one go
+// (0.43 -> 0.2x ms on 1024 x 224 x 224 images: the per-chunk kernel was bound by its byte loads and index arithmetic).
+template <typename TO>
+__global__ __launch_bounds__(128) void to_s2d_u8_rows_kernel(const uint8_t* __restrict__ x, TO* __restrict__ y, int H2,
+                                                             int W2, const float* __restrict__ mean255,
+                                                             const float* __restrict__ inv_std255, int padl, int padr) {
+  static_assert(sizeof(TO) == 2, "16-bit outputs");
+  const int WP = W2 + padl + padr;
+  const long rowid = blockIdx.x;                       // n * H2 + Y
+  const long n = rowid / H2;
+  const int Y = (int)(rowid - n * H2);
+  const int W = 2 * W2, H = 2 * H2;
+  float mu[3], is[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { mu[c] = mean255[c]; is[c] = inv_std255[c]; }
+  const uint8_t* r0 = x + ((n * H + 2 * Y) * W) * 3;
+  const uint8_t* r1 = r0 + (long)W * 3;
+  for (int xp = threadIdx.x; xp < WP; xp += blockDim.x) {
+    const int X = xp - padl;
+    Vec16<TO> o0, o1;
+    o0.raw = make_uint4(0u, 0u, 0u, 0u);
+    o1.raw = make_uint4(0u, 0u, 0u, 0u);
+    if (X >= 0 && X < W2) {
+      const uint16_t* p0 = reinterpret_cast<const uint16_t*>(r0 + 6 * X);
+      const uint16_t* p1 = reinterpret_cast<const uint16_t*>(r1 + 6 * X);
+      const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+      const uint32_t v[12] = {a0 & 255u, a0 >> 8, a1 & 255u, a1 >> 8, a2 & 255u, a2 >> 8,
+                              b0 & 255u, b0 >> 8, b1 & 255u, b1 >> 8, b2 & 255u, b2 >> 8};
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) o0.set(ch, ((float)v[ch] - mu[ch % 3]) * is[ch % 3]);
+#pragma unroll
+      for (int ch = 8; ch < 12; ++ch) o1.set(ch - 8, ((float)v[ch] - mu[ch % 3]) * is[ch % 3]);
+    }
+    TO* dst = y + (rowid * WP + xp) * 16;
+    o0.store(dst);
+    o1.store(dst + 8);
+  }
+}
+
 // float-ish NCHW -> NHWC with channel padding (LDS-free: C is tiny (3) for images)
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const TI* __restrict__ x, TO* __restrict__ y, int NB, int C,
@@ -436,6 +477,16 @@ void to_s2d_launch(const void* x, void* y, int NB, int H2, int W2, int nchw, int
   if (total <= 0) return;
   if (in_dtype < 0) {      // uint8 source
     if (mean255 == nullptr || inv_std255 == nullptr) throw std::invalid_argument("to_s2d: uint8 input needs mean / std");
+    if (!nchw && out_dtype != kF32 && (long)NB * H2 < 2147483647l && ((uintptr_t)x & 1) == 0) {
+      if (out_dtype == kBF16)
+        hipLaunchKernelGGL(to_s2d_u8_rows_kernel<bf16_t>, dim3((unsigned)((long)NB * H2)), dim3(128), 0, s,
+                           (const uint8_t*)x, (bf16_t*)y, H2, W2, mean255, inv_std255, padl, padr);
+      else
+        hipLaunchKernelGGL(to_s2d_u8_rows_kernel<f16_t>, dim3((unsigned)((long)NB * H2)), dim3(128), 0, s,
+                           (const uint8_t*)x, (f16_t*)y, H2, W2, mean255, inv_std255, padl, padr);
+      DPA_CHECK_HIP(hipGetLastError());
+      return;
+    }
     DPA_DISPATCH_DTYPE(out_dtype, hipLaunchKernelGGL((to_s2d_kernel<uint8_t, T, true>), dim3(grid_for(total)), dim3(256),
                                                      0, s, (const uint8_t*)x, (T*)y, NB, H2, W2, nchw, mean255,
                                                      inv_std255, padl, padr));
