@@ -15,6 +15,11 @@
 // dY that are zero multiply whatever sits in the corresponding activation entries, so no mask is applied anywhere in
 // the MFMA loop.  SEG is a multiple of the MFMA K step (16): 12.5 % of the slots are padding for W = 7, 14, 28, 56.
 //
+// Wide images (W = NCH * W', NCH = 2 / 4, 33 <= W' <= 64: 112 = 2 x 56, 224 = 4 x 56 -- VGG) are walked as NCH "virtual
+// rows" per image row: a virtual row is a contiguous run of W' pixels, so the addressing is that of an image of width
+// W' with H * NCH rows, except that (a) the vertical tap shift is NCH virtual rows and (b) the two extra entries of a
+// staged activation segment are real pixels of the neighbouring chunk unless the chunk touches the image border.
+//
 // Pixel-major LDS tiles + gfx950 transposed reads, fp32 partial slabs [splits][N][R*3*Cred] and the deterministic slab
 // fold are those of wgrad.hip.  Replaces cuDNN's backward-filter for the 3x3 layers (reference: loss.backward(),
 // nd_imagenet.py:302) -- SURVEY.md N-K3.
@@ -41,6 +46,7 @@ struct Row3Params {
   int NB, H, W, N, Cred, R, ph, ldy, ldx;
   int splits, rows_per_split;     // image rows (NB*H of them) per split: a multiple of the rows of a K tile
   int RS, WP;          // image rows per segment, slot stride of a row inside the segment (SEG when RS == 1)
+  int NCH;             // virtual rows per image row (1, 2, 4); H and W above are then H * NCH and W / NCH
 };
 
 template <typename T, int BI, int WI, int WJ, int SEG, int RPT>
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_row3_kernel(const Row3Para
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
   const int r = tj / ncb, c0 = (tj - r * ncb) * CJ;
   const int i0 = ti * BI;
-  const int dy = r - p.ph;
+  const int dy = (r - p.ph) * p.NCH;                   // vertical tap shift in (virtual) rows
   const int NR = p.NB * p.H;
   const int row_begin = split * p.rows_per_split;
   const int row_end = min(NR, row_begin + p.rows_per_split);
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_row3_kernel(const Row3Para
   const char* __restrict__ Yl = reinterpret_cast<const char*>(p.dY) + (size_t)row_begin * p.W * p.ldy * sizeof(T);
   // the activation base sits one image row + one pixel EARLIER when dy = -1 ...: offsets below stay non-negative by
   // basing at the split's first row shifted by dy (rows before the tensor are never dereferenced: masked)
-  const char* __restrict__ Xl = reinterpret_cast<const char*>(p.X) + ((long)row_begin + dy) * p.W * (long)p.ldx * (long)sizeof(T);
+  // (and one PIXEL earlier: entry 0 of a segment is the pixel left of its first slot)
+  const char* __restrict__ Xl = reinterpret_cast<const char*>(p.X) + (((long)row_begin + dy) * p.W - 1) * (long)p.ldx * (long)sizeof(T);
 
   // ---- dY staging: fixed (slot, chunk) per thread and iteration
   uint32_t poff[P_IT];
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_row3_kernel(const Row3Para
   // ---- activation staging: entry e of segment q holds slot e - 1
   uint32_t qoff[Q_IT];
   int qrow[Q_IT], qy[Q_IT];            // relative image row (< 0: a zero entry), its y coordinate (advanced per K tile)
+  int qhalo[Q_IT];                     // NCH > 1: -1 / +1 = the entry left / right of the chunk (valid unless at the border)
 #pragma unroll
   for (int it = 0; it < Q_IT; ++it) {
     const int idx = tid + it * NT;
@@ -106,11 +114,13 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_row3_kernel(const Row3Para
     const int q = qr / (SEG + 2), e = qr % (SEG + 2);
     const int k = e - 1;
     const int j = (p.RS > 1 && k >= 0) ? k / p.WP : 0, x = (p.RS > 1 && k >= 0) ? k - j * p.WP : k;
-    const bool ok = qr < QR && k >= 0 && x < p.W && j < p.RS;
+    const bool inner = qr < QR && k >= 0 && x < p.W && j < p.RS;
+    qhalo[it] = (qr < QR && p.NCH > 1) ? (k < 0 ? -1 : (k == p.W ? 1 : 0)) : 0;
+    const bool ok = inner || qhalo[it] != 0;
     const int rel = q * p.RS + j;
     qrow[it] = ok ? rel : -1;
     qy[it] = ok ? (row_begin + rel) % p.H : 0;
-    qoff[it] = ok ? (uint32_t)(((rel * p.W + x) * p.ldx + c0 + cq * 8) * (int)sizeof(T)) : 0u;
+    qoff[it] = ok ? (uint32_t)(((rel * p.W + x + 1) * p.ldx + c0 + cq * 8) * (int)sizeof(T)) : 0u;
   }
   const uint32_t pstep = (uint32_t)(rows_per_tile * p.W * p.ldy * (int)sizeof(T));
   const uint32_t qstep = (uint32_t)(rows_per_tile * p.W * p.ldx * (int)sizeof(T));
@@ -128,7 +138,9 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_row3_kernel(const Row3Para
     }
 #pragma unroll
     for (int it = 0; it < Q_IT; ++it) {
-      const bool ok = qrow[it] >= 0 && row0 + qrow[it] < row_end && (unsigned)(qy[it] + dy) < (unsigned)p.H;
+      const int chunk = qy[it] & (p.NCH - 1);        // NCH is a power of two and divides the rows per image
+      const bool ok = qrow[it] >= 0 && row0 + qrow[it] < row_end && (unsigned)(qy[it] + dy) < (unsigned)p.H &&
+                      (qhalo[it] == 0 || (qhalo[it] < 0 ? chunk != 0 : chunk != p.NCH - 1));
       qmask[it] = ok ? 0xffffffffu : 0u;
       rq[it] = *reinterpret_cast<const uint4*>(ok ? Xl + qoff[it] : reinterpret_cast<const char*>(p.X));
       qoff[it] += qstep;
@@ -283,7 +295,16 @@ void dispatch_row3w(const Row3Params& p, hipStream_t stream) {
 int g_row3w_mode = -1;      // -1 automatic (output-channel counts where it measured faster than wgrad.hip), 0 never, 1 whenever covered
 
 // segment geometry for an image width: false = not covered
-bool row3w_geometry(int W, int* seg, int* rpt, int* rs, int* wp) {
+bool row3w_geometry(int W, int* seg, int* rpt, int* rs, int* wp, int* nch) {
+  *nch = 1;
+  if (W > 64) {         // wide images as 2 / 4 chunks of 33..64 pixels per row
+    int n = 0;
+    if (W % 2 == 0 && W / 2 >= 33 && W / 2 <= 64) n = 2;
+    else if (W % 4 == 0 && W / 4 >= 33 && W / 4 <= 64) n = 4;
+    if (n == 0) return false;
+    *nch = n; *seg = 64; *rpt = 1; *rs = 1; *wp = 64;
+    return true;
+  }
   if (W == 7) { *seg = 16; *rpt = 4; *rs = 2; *wp = 8; return true; }           // two rows + a zero slot each per segment
   if (W >= 8 && W <= 16) { *seg = 16; *rpt = 4; *rs = 1; *wp = 16; return true; }
   if (W >= 17 && W <= 32) { *seg = 32; *rpt = 2; *rs = 1; *wp = 32; return true; }
@@ -300,15 +321,15 @@ void wgrad_row3_set_variant(int v) { g_row3w_variant = v; }
 
 // Splits of the image rows for the filter-row weight gradient; 0 = the problem is not covered (use wgrad_launch).
 int wgrad_row3_splits(int NB, int H, int W, int N, int Cred, int R, int dtype, int* rows_per_split) {
-  int seg, rpt, rs, wp;
+  int seg, rpt, rs, wp, nch;
   if (g_row3w_mode == 0 || dtype == kF32 || Cred % 64 != 0 || N % 8 != 0 || R < 1 || R > 7 || R % 2 == 0) return 0;
-  if (!row3w_geometry(W, &seg, &rpt, &rs, &wp)) return 0;
+  if (!row3w_geometry(W, &seg, &rpt, &rs, &wp, &nch)) return 0;
   // measured (profiles/r3/wgrad_row3_layers.txt): 1.46x on N = 64, 0.75x on N >= 128 where the 256 x 128 tile of wgrad.hip
   // already runs at 620..800 TFLOP/s and the split count here is capped by the slab size
   if (g_row3w_mode < 0 && N > 64) return 0;
-  const long NR = (long)NB * H;
+  const long NR = (long)NB * H * nch;                  // (virtual) rows
   const int rows_per_tile = rpt * rs;
-  if (NR < 2l * rows_per_tile) return 0;
+  if (NR < 2l * rows_per_tile || NR >= (1l << 31)) return 0;
   const int bi = row3w_tile_bi(N);
   const long tiles = (long)ceil_div(N, bi) * R * (Cred / 64);
   const long target = 768l * 256 / (bi == 256 ? 512 : 256);
@@ -330,13 +351,15 @@ void wgrad_row3_launch(const void* dY, const void* X, float* slab, int NB, int H
                        int ldy, int ldx, int splits, int rows_per_split, int dtype, hipStream_t stream) {
   Row3Params p{};
   int seg, rpt;
-  if (!row3w_geometry(W, &seg, &rpt, &p.RS, &p.WP) || dtype == kF32 || Cred % 64 != 0 || N % 8 != 0 || ldy % 8 != 0 ||
+  if (!row3w_geometry(W, &seg, &rpt, &p.RS, &p.WP, &p.NCH) || dtype == kF32 || Cred % 64 != 0 || N % 8 != 0 || ldy % 8 != 0 ||
       ldx % 8 != 0 || R < 1 || R > 7 || ph < 0 || ph >= R)
     throw std::invalid_argument("wgrad_row3: problem not covered (ask wgrad_row3_splits first)");
-  if (splits < 1 || rows_per_split % (rpt * p.RS) != 0 || (long)splits * rows_per_split < (long)NB * H)
+  if (splits < 1 || rows_per_split % (rpt * p.RS) != 0 || (long)splits * rows_per_split < (long)NB * H * p.NCH)
     throw std::invalid_argument("wgrad_row3: bad split of the image rows");
+  H *= p.NCH;          // virtual rows per image ...
+  W /= p.NCH;          // ... of W' pixels
   // 32-bit offsets inside one split (+ two K tiles of lookahead, + the filter's vertical reach)
-  const double span = ((double)rows_per_split + 2.0 * rpt * p.RS + R) * W * 2.0;
+  const double span = ((double)rows_per_split + 2.0 * rpt * p.RS + (double)R * p.NCH) * W * 2.0;
   if (span * ldy >= 4294967296.0 || span * ldx >= 4294967296.0)
     throw std::invalid_argument("wgrad_row3: a split spans more than 4 GiB");
   p.dY = dY; p.X = X; p.slab = slab;

@@ -1,5 +1,5 @@
 """Filter-row weight gradient (csrc/kernels/wgrad_row3.hip) against the fp32 PyTorch reference and against wgrad.hip:
-every segment geometry (W = 7: two rows per segment; 8..16, 17..32, 33..64), every tile width, filter heights 1 / 3 / 5,
+every segment geometry (W = 7: two rows per segment; 8..16, 17..32, 33..64; wide images as 2 / 4 chunks per row), every tile width, filter heights 1 / 3 / 5,
 ragged row splits."""
 import pytest
 import torch
@@ -17,6 +17,8 @@ CASES = [
     (9, 7, 7, 64, 64, 3), (5, 14, 14, 128, 256, 3), (3, 28, 28, 64, 128, 3), (2, 56, 56, 64, 64, 3),
     (4, 9, 11, 64, 320, 3), (2, 20, 20, 192, 72, 3), (2, 12, 33, 64, 128, 3), (6, 8, 8, 128, 128, 1),
     (3, 17, 17, 64, 64, 5), (4, 13, 64, 64, 256, 3),
+    # wide images: 2 / 4 virtual rows of 33..64 pixels per image row (VGG conv1_2 / conv2_x geometry)
+    (2, 10, 112, 64, 64, 3), (1, 6, 224, 64, 64, 3), (2, 5, 80, 64, 128, 3), (1, 4, 136, 128, 64, 3), (2, 7, 96, 64, 64, 5),
 ]
 
 
