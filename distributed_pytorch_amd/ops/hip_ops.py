@@ -322,6 +322,28 @@ def _colsum(dy2d: torch.Tensor) -> torch.Tensor:
     return s1
 
 
+def _bias_grad(bias_p, dy2d: torch.Tensor, keep=None):
+    """Gradient of a bias = column sums of the [M, C >= keep] output gradient, handed to the parameter's sink (returns
+    None) or to autograd.  When the sink has not been written this iteration the fold of the partial sums writes
+    straight into its view: two launches instead of three (+ two temporaries).  A one-launch variant (in-kernel ordered
+    fold behind a ticket) measured slower: wide enough for the bandwidth it leaves a long serial fold to one workgroup
+    (56 us), narrow enough for the fold it pays an L2 write-back per workgroup (profiles/r3_notes.md)."""
+    M, Cc = dy2d.shape
+    keep = Cc if keep is None else keep
+    sink = grad_sink.sink_of(bias_p)
+    if sink is not None and keep == Cc and sink.beta() == 0.0 and sink.view.is_contiguous() and sink.view.numel() == Cc \
+            and dy2d.is_contiguous():
+        nblk = C().bn_partial_rows(M, Cc)
+        part = _stats_slab(nblk, Cc, dy2d.device)
+        st = _stream()
+        C().bn_stats(dy2d.data_ptr(), M, Cc, _dt(dy2d), part.data_ptr(), nblk, st)
+        s2 = torch.empty(Cc, dtype=torch.float32, device=dy2d.device)
+        C().bn_bwd_finalize(part.data_ptr(), nblk, Cc, s2.data_ptr(), sink.view.data_ptr(), st)
+        sink.delivered()
+        return None
+    return _deliver(bias_p, _colsum(dy2d if dy2d.is_contiguous() else dy2d.contiguous())[:keep].to(bias_p.dtype))
+
+
 def _flat_same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
     if a.shape != b.shape:
         return False
@@ -960,7 +982,7 @@ class _ConvFn(torch.autograd.Function):
             dw = conv_wgrad(dy, x, weight, (sh, sw), (ph, pw), axf=axf)
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
-            db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
+            db = _bias_grad(bias_p, dy.view(M, K))
         return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
@@ -1524,7 +1546,7 @@ class _GroupConvFn(torch.autograd.Function):
                 dw = _deliver(weight, g.to(weight.dtype))
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
-            db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
+            db = _bias_grad(bias_p, dy.view(M, K))
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -1609,7 +1631,7 @@ class _DepthwiseConvFn(torch.autograd.Function):
                 dw = _deliver(weight, full.to(weight.dtype))
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
-            db = _deliver(bias_p, _colsum(dy.view(NB * OH * OW, K)).to(bias_p.dtype))
+            db = _bias_grad(bias_p, dy.view(NB * OH * OW, K))
         return dx, dw, db, None, None, None, None, None
 
 
@@ -2870,7 +2892,7 @@ class _LinearFn(torch.autograd.Function):
                 dw = _deliver(weight, full[:out_f])
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
-            db = _deliver(bias_p, _colsum(dyp)[:out_f].to(bias_p.dtype))
+            db = _bias_grad(bias_p, dyp, out_f)
         return dx, dw, db, None, None
 
 
@@ -3125,7 +3147,7 @@ class _StemS2DFn(torch.autograd.Function):
             dw = _deliver(weight, g.to(weight.dtype))
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
-            db = _deliver(bias_p, _colsum(dy.view(M, K)).to(bias_p.dtype))
+            db = _bias_grad(bias_p, dy.view(M, K))
         return None, dw, db, None, None
 
 
