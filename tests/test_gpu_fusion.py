@@ -286,3 +286,27 @@ def test_strided_data_gradient_reduces_bn_backward_sums_in_its_parity_classes(sh
     got, want = ent[0].sum(0), part.sum(0)
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 1e-4 * scale, (got - want).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(6, 64, 3, 32), (3, 50, 12, 64), (2, 33, 2, 128), (5, 49, 4, 24)])
+def test_cosine_attention_prepass(shape, dtype):
+    """q <- mult[h] * q / |q|, k <- k / |k|, v unchanged (Swin V2), forward and backward: the one-lane-per-chunk kernel
+    (D = 32 / 64 / 128) and the thread-per-vector fallback (D = 24) against PyTorch in fp32."""
+    B, S, H, D = shape
+    torch.manual_seed(9)
+    qkv = torch.randn(B, S, 3 * H * D, device=DEV).to(dtype).requires_grad_(True)
+    mult = (torch.rand(H, device=DEV) * 4 + 1).requires_grad_(True)
+    y = F.qk_normalize(qkv, mult, H)
+    gy = torch.randn(y.shape, device=DEV).to(dtype)
+    y.backward(gy)
+    qr = qkv.detach().float().requires_grad_(True)
+    mr = mult.detach().clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, S, 3, H, D).unbind(2)
+    qn = mr.reshape(1, 1, H, 1) * q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    kn = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    yr = torch.stack([qn, kn, v], 2).reshape(B, S, 3 * H * D)
+    yr.backward(gy.float())
+    assert_close(y, yr, dtype, what="out", scale=2)
+    assert_close(qkv.grad, qr.grad, dtype, what="dqkv", scale=4)
+    assert torch.allclose(mult.grad, mr.grad, rtol=3e-2, atol=3e-2 * mr.grad.abs().max().item())
