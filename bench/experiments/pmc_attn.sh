@@ -6,9 +6,10 @@ mkdir -p $R/gpurun_out/r3
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/r3/pmc_attn1 -- python3 $R/bench/experiments/attn_pmc.py > $R/gpurun_out/r3/pmc_attn1.log 2>&1
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/r3/pmc_attn2 -- python3 $R/bench/experiments/attn_pmc.py > $R/gpurun_out/r3/pmc_attn2.log 2>&1
 cd $R
-python3 - <<'PY' | tee gpurun_out/r3/pmc_attn.md
+python3 - <<'PY' | tee gpurun_out/r3/${PMC_OUT:-pmc_attn}.md
 import csv, glob, collections
-print("# rocprofv3 --pmc, fused attention at the ViT-B/16 shape (b128, S 197, 12 heads x 64); per dispatch means\n")
+import os
+print("# rocprofv3 --pmc, fused attention, shape B,S,H,D = %s (windows %s); per dispatch means\n" % (os.environ.get("ATTN_SHAPE", "128,197,12,64"), os.environ.get("ATTN_WINDOWS", "0")))
 for tag in ("pmc_attn1", "pmc_attn2"):
     f = glob.glob("gpurun_out/r3/%s/**/*counter_collection.csv" % tag, recursive=True)[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
