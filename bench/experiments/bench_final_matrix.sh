@@ -4,11 +4,11 @@ mkdir -p gpurun_out/${ROUND:-r2}
 out=gpurun_out/${ROUND:-r2}/bench_matrix_final_$1.txt; : > $out
 run() { timeout -k 10 240 python bench.py "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '->', d['value'], d['ms_per_step'], d['config'].get('peak_mem_gb'))" | tee -a $out || exit 1; }
 if [ "$1" = "1" ]; then
-run --steps 20 --warmup 8
+run --steps 20 --warmup 8 --batch-size 1024
 run --steps 20 --warmup 8 --batch-size 256
 run --steps 10 --warmup 4 --batch-size 2048
-run --steps 20 --warmup 8 --force-ddp
-run --steps 20 --warmup 8 --force-ddp --sync-bn
+run --steps 20 --warmup 8 --batch-size 1024 --force-ddp
+run --steps 20 --warmup 8 --batch-size 1024 --force-ddp --sync-bn
 run --steps 20 --warmup 8 --batch-size 256 --dtype fp16
 run --steps 10 --warmup 4 --batch-size 256 --dtype fp32
 run --steps 20 --warmup 8 --arch resnet18 --batch-size 256
